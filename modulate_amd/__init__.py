@@ -1,0 +1,14 @@
+"""modulate_amd -- MI355X (gfx950) implementation of Modulate's cipher hot path.
+
+The product is the C-ABI shared library ``libmodgpu.so`` (include/modgpu.h), built from
+``modulate_amd/csrc`` with hipcc, plus the C++ host mirror of the reference surface
+(``CEncryptionCycler``, the ``CArk`` buffer path) in ``libmodulate_host.so``.  This Python
+package is only a ctypes binding over those libraries for the test-suite and ``bench.py``;
+there is no Python or CPU implementation of the cipher in it, and importing the bindings fails
+loudly if the HIP library has not been built.
+"""
+from .capi import (  # noqa: F401
+    ModGpuError, lib, lib_path, device_count, cycle_host, cycle_device, hdr_decrypt_host,
+    hdr_encrypt_host, cycle_parts_host, DeviceBuffer, time_cycle_device, state_at, jump_table,
+    KEY_PS3, KEY_PS4, MAGIC_PS3, MAGIC_PS4, as_int32, EXPORTS,
+)

@@ -1,0 +1,172 @@
+"""ctypes binding over libmodgpu.so -- every call goes through the C ABI of include/modgpu.h.
+
+No fallback: if the library is missing or a call fails, ModGpuError is raised.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+KEY_PS3 = 0xC64EED30  # Modulate/Settings.h:19
+KEY_PS4 = 0x90CFC0AB  # Modulate/Settings.h:20
+MAGIC_PS3 = 0xC64EED30  # Modulate/Settings.h:16
+MAGIC_PS4 = 0x6F303F55  # Modulate/Settings.h:17
+
+# every symbol include/modgpu.h declares: (name, restype, argtypes)
+_u64, _i32, _int, _vp = ctypes.c_uint64, ctypes.c_int32, ctypes.c_int, ctypes.c_void_p
+EXPORTS = {
+    "modgpu_abi_version": (_int, []),
+    "modgpu_device_count": (_int, []),
+    "modgpu_last_error": (ctypes.c_char_p, []),
+    "modgpu_cycle_device": (_int, [_vp, _u64, _i32, _u64, _int, _vp]),
+    "modgpu_cycle_host": (_int, [_vp, _u64, _i32, _u64, _int]),
+    "modgpu_hdr_decrypt_host": (_int, [_vp, _u64, _int]),
+    "modgpu_hdr_encrypt_host": (_int, [_vp, _u64, _int, _int]),
+    "modgpu_cycle_parts_host": (_int, [ctypes.POINTER(_vp), ctypes.POINTER(_u64), _int, _i32, _int]),
+    "modgpu_alloc": (_int, [ctypes.POINTER(_vp), _u64, _int]),
+    "modgpu_free": (_int, [_vp, _int]),
+    "modgpu_h2d": (_int, [_vp, _vp, _u64, _int]),
+    "modgpu_d2h": (_int, [_vp, _vp, _u64, _int]),
+    "modgpu_sync": (_int, [_int, _vp]),
+    "modgpu_time_cycle_device": (_int, [_vp, _u64, _i32, _u64, _int, _vp, _int, ctypes.POINTER(ctypes.c_float)]),
+    "modgpu_state_at": (ctypes.c_uint32, [_i32, _u64]),
+    "modgpu_jump_table": (_int, [_int, ctypes.POINTER(ctypes.c_uint32), _int]),
+}
+
+
+class ModGpuError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"modgpu error {code}: {text}")
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "libmodgpu.so")
+
+
+_lib = None
+
+
+def lib():
+    """The loaded libmodgpu.so.  Raises if it was not built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ModGpuError(-1, f"{path} not built: run `make -C modulate_amd/csrc` (there is no CPU fallback)")
+        L = ctypes.CDLL(path)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def as_int32(key):
+    key &= 0xFFFFFFFF
+    return key - (1 << 32) if key & 0x80000000 else key
+
+
+def _check(rc):
+    if rc != 0:
+        raise ModGpuError(rc, lib().modgpu_last_error().decode())
+
+
+def _host_ptr(a):
+    if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"] and a.flags["WRITEABLE"]):
+        raise TypeError("need a writable C-contiguous uint8 ndarray")
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def device_count():
+    return lib().modgpu_device_count()
+
+
+def cycle_host(buf, key, stream_off=0, device=-1):
+    """In-place CEncryptionCycler::Cycle over a host ndarray, computed on the GPU."""
+    _check(lib().modgpu_cycle_host(_host_ptr(buf), buf.size, as_int32(key), stream_off, device))
+    return buf
+
+
+def hdr_decrypt_host(hdr, device=-1):
+    _check(lib().modgpu_hdr_decrypt_host(_host_ptr(hdr), hdr.size, device))
+    return hdr
+
+
+def hdr_encrypt_host(hdr, ps4=True, device=-1):
+    _check(lib().modgpu_hdr_encrypt_host(_host_ptr(hdr), hdr.size, 1 if ps4 else 0, device))
+    return hdr
+
+
+def cycle_parts_host(parts, key, n_devices=0):
+    n = len(parts)
+    ptrs = (_vp * n)(*[_host_ptr(p).value for p in parts])
+    sizes = (_u64 * n)(*[p.size for p in parts])
+    _check(lib().modgpu_cycle_parts_host(ptrs, sizes, n, as_int32(key), n_devices))
+    return parts
+
+
+def cycle_device(dev_ptr, n, key, stream_off=0, device=-1, stream=None):
+    """Asynchronous in-place cycle of n device-resident bytes at raw address dev_ptr."""
+    _check(lib().modgpu_cycle_device(_vp(dev_ptr), n, as_int32(key), stream_off, device, _vp(stream or 0)))
+
+
+def time_cycle_device(dev_ptr, n, key, stream_off=0, device=-1, stream=None, iters=2):
+    """Mean ms per launch over `iters` launches, HIP events on the launch stream."""
+    ms = ctypes.c_float(0)
+    _check(lib().modgpu_time_cycle_device(_vp(dev_ptr), n, as_int32(key), stream_off, device, _vp(stream or 0),
+                                          iters, ctypes.byref(ms)))
+    return ms.value
+
+
+def state_at(key, i):
+    return lib().modgpu_state_at(as_int32(key), i)
+
+
+def jump_table(which):
+    out = (ctypes.c_uint32 * 256)()
+    n = lib().modgpu_jump_table(which, out, 256)
+    return list(out[:n])
+
+
+class DeviceBuffer:
+    """hipMalloc'd bytes owned through modgpu_alloc / modgpu_free."""
+
+    def __init__(self, nbytes, device=-1):
+        self.nbytes, self.device = nbytes, device
+        p = _vp()
+        _check(lib().modgpu_alloc(ctypes.byref(p), nbytes, device))
+        self.ptr = p.value
+
+    def upload(self, host, offset=0):
+        host = np.ascontiguousarray(host, dtype=np.uint8)
+        assert offset + host.size <= self.nbytes
+        _check(lib().modgpu_h2d(_vp(self.ptr + offset), _vp(host.ctypes.data), host.size, self.device))
+
+    def download(self, n=None, offset=0):
+        n = self.nbytes - offset if n is None else n
+        out = np.empty(n, dtype=np.uint8)
+        _check(lib().modgpu_d2h(_vp(out.ctypes.data), _vp(self.ptr + offset), n, self.device))
+        return out
+
+    def cycle(self, key, n=None, offset=0, stream_off=0, stream=None):
+        n = self.nbytes - offset if n is None else n
+        assert offset + n <= self.nbytes
+        cycle_device(self.ptr + offset, n, key, stream_off, self.device, stream)
+
+    def sync(self, stream=None):
+        _check(lib().modgpu_sync(self.device, _vp(stream or 0)))
+
+    def free(self):
+        if self.ptr:
+            _check(lib().modgpu_free(_vp(self.ptr), self.device))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,383 @@
+// modgpu_capi.cpp -- host side of the C ABI in include/modgpu.h.
+//
+// Compiled by hipcc as host-only C++ and linked with cycle_kernel.hip into libmodgpu.so.
+// No CPU implementation of the cipher lives here: the only arithmetic done on the host is the
+// per-launch jump-ahead (a handful of modular powers) that seeds the kernel.
+#include "../../include/modgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "cycle_kernel.h"
+#include "lcg.h"
+
+namespace {
+
+thread_local std::string t_err;
+
+int fail(int code, const char *what)
+{
+    t_err = what;
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *where)
+{
+    t_err = std::string(where) + ": " + hipGetErrorString(e);
+    return MODGPU_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail_hip(e_, #expr);                                          \
+    } while (0)
+
+int device_count_raw()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+// Makes `device` current for the calling thread (HIP's current device is per thread).
+int select_device(int device)
+{
+    int n = device_count_raw();
+    if (n <= 0) return fail(MODGPU_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0) return MODGPU_OK; // keep the thread's current device
+    if (device >= n) return fail(MODGPU_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    return MODGPU_OK;
+}
+
+int resolve_device(int device, int *out)
+{
+    int rc = select_device(device);
+    if (rc) return rc;
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    *out = device;
+    return MODGPU_OK;
+}
+
+// ---- launch planning -----------------------------------------------------------------
+
+struct Plan {
+    CycleArgs args;
+    int unroll;
+    uint32_t grid;
+};
+
+constexpr uint32_t kMaxGrid = 256u * 8u; // 256 CUs x 8 resident 256-thread blocks
+
+// Splits [buf, buf+n) into <16 head bytes, an aligned body of 16-byte words and <16 tail bytes,
+// and computes the states that seed each piece.  key_res != 0.
+Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off)
+{
+    Plan p{};
+    uintptr_t addr = reinterpret_cast<uintptr_t>(dev_buf);
+    uint64_t head = std::min<uint64_t>(n, (16 - (addr & 15)) & 15);
+    uint64_t words = (n - head) / 16;
+    uint64_t tail = n - head - words * 16;
+    // the stream position of byte j is stream_off + j; positions reduce mod PERIOD
+    uint64_t o = stream_off % lcg::PERIOD;
+
+    CycleArgs &a = p.args;
+    a.head_ptr = static_cast<uint8_t *>(dev_buf);
+    a.head_n = (uint32_t)head;
+    a.body = a.head_ptr + head;
+    a.body_words = words;
+    a.tail_ptr = a.head_ptr + head + words * 16;
+    a.tail_n = (uint32_t)tail;
+    a.base_head = lcg::state_residue(key_res, o);
+    a.base_body = lcg::state_residue(key_res, o + head);
+    a.base_tail = lcg::state_residue(key_res, o + head + (words * 16) % lcg::PERIOD);
+
+    // words per block-trip = 256 * unroll.  Small bodies: one word per thread, enough blocks to
+    // cover it; large: 4 words per thread per trip and a grid that fills the chip 8 deep.
+    uint64_t tiles = (words + lcg::BLOCK - 1) / lcg::BLOCK;
+    p.unroll = tiles >= 4ull * kMaxGrid ? 4 : (tiles >= 2ull * kMaxGrid ? 2 : 1);
+    uint64_t blocks = (tiles + p.unroll - 1) / p.unroll;
+    p.grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, kMaxGrid));
+    // one grid trip advances every lane-word by grid*unroll tiles of 4096 bytes
+    a.stride_mul = lcg::powmod(lcg::A, ((uint64_t)p.grid * p.unroll * lcg::TILE) % lcg::PERIOD);
+    return p;
+}
+
+int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off, hipStream_t stream)
+{
+    if (n == 0) return MODGPU_OK;
+    if (!dev_buf) return fail(MODGPU_ERR_INVALID, "null device buffer");
+    uint32_t key_res = lcg::key_residue(key);
+    if (key_res == 0) return MODGPU_OK; // keystream is all zero (state sticks at m): identity
+    Plan p = plan_cycle(dev_buf, n, key_res, stream_off);
+    hipError_t e = modgpu_launch_cycle(p.args, p.unroll, p.grid, stream);
+    if (e != hipSuccess) return fail_hip(e, "cycle kernel launch");
+    return MODGPU_OK;
+}
+
+// ---- per-device staging context for host-buffer calls ----------------------------------
+
+constexpr uint64_t kChunk = 32ull << 20; // bytes per pipeline stage
+constexpr int kSlots = 3;                // pinned+device slots in flight
+
+struct Staging {
+    std::mutex mu;
+    bool ready = false;
+    uint8_t *pinned[kSlots] = {};
+    uint8_t *dev[kSlots] = {};
+    hipStream_t stream[kSlots] = {};
+    uint64_t cap = 0;
+};
+
+constexpr int kMaxDevices = 64;
+Staging g_staging[kMaxDevices];
+
+int staging_reserve(Staging &s, uint64_t need)
+{
+    need = std::min<uint64_t>(std::max<uint64_t>(need, 1ull << 20), kChunk);
+    if (s.ready && s.cap >= need) return MODGPU_OK;
+    for (int i = 0; i < kSlots; ++i) {
+        if (s.pinned[i]) HIP_TRY(hipHostFree(s.pinned[i]));
+        if (s.dev[i]) HIP_TRY(hipFree(s.dev[i]));
+        s.pinned[i] = nullptr;
+        s.dev[i] = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.pinned[i]), need, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev[i]), need));
+        if (!s.stream[i]) HIP_TRY(hipStreamCreateWithFlags(&s.stream[i], hipStreamNonBlocking));
+    }
+    s.cap = need;
+    s.ready = true;
+    return MODGPU_OK;
+}
+
+// H2D -> kernel -> D2H, chunked over kSlots streams so copies in both directions overlap the
+// kernel and the host-side memcpy into / out of pinned memory.
+int cycle_host_impl(uint8_t *host, uint64_t n, int32_t key, uint64_t stream_off, int device)
+{
+    if (n == 0) return MODGPU_OK;
+    if (!host) return fail(MODGPU_ERR_INVALID, "null host buffer");
+    int dev = 0;
+    int rc = resolve_device(device, &dev);
+    if (rc) return rc;
+    if (lcg::key_residue(key) == 0) return MODGPU_OK; // identity, as in the reference
+    if (dev >= kMaxDevices) return fail(MODGPU_ERR_INVALID, "device index beyond staging table");
+    Staging &s = g_staging[dev];
+    std::lock_guard<std::mutex> lock(s.mu);
+    rc = staging_reserve(s, n);
+    if (rc) return rc;
+
+    const uint64_t chunk = s.cap;
+    const uint64_t n_chunks = (n + chunk - 1) / chunk;
+    auto span = [&](uint64_t c, uint64_t *off, uint64_t *len) {
+        *off = c * chunk;
+        *len = std::min<uint64_t>(chunk, n - *off);
+    };
+    for (uint64_t c = 0; c < n_chunks + kSlots; ++c) {
+        int slot = (int)(c % kSlots);
+        if (c >= kSlots) { // drain the chunk that used this slot kSlots trips ago
+            uint64_t off, len;
+            span(c - kSlots, &off, &len);
+            HIP_TRY(hipStreamSynchronize(s.stream[slot]));
+            std::memcpy(host + off, s.pinned[slot], len);
+        }
+        if (c < n_chunks) {
+            uint64_t off, len;
+            span(c, &off, &len);
+            std::memcpy(s.pinned[slot], host + off, len);
+            HIP_TRY(hipMemcpyAsync(s.dev[slot], s.pinned[slot], len, hipMemcpyHostToDevice, s.stream[slot]));
+            rc = cycle_device_impl(s.dev[slot], len, key, stream_off + off, s.stream[slot]);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(s.pinned[slot], s.dev[slot], len, hipMemcpyDeviceToHost, s.stream[slot]));
+        }
+    }
+    return MODGPU_OK;
+}
+
+uint32_t load_le32(const uint8_t *p)
+{
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+void store_le32(uint8_t *p, uint32_t v)
+{
+    p[0] = (uint8_t)v;
+    p[1] = (uint8_t)(v >> 8);
+    p[2] = (uint8_t)(v >> 16);
+    p[3] = (uint8_t)(v >> 24);
+}
+
+} // namespace
+
+extern "C" {
+
+int modgpu_abi_version(void) { return MODGPU_ABI_VERSION; }
+
+int modgpu_device_count(void) { return device_count_raw(); }
+
+const char *modgpu_last_error(void) { return t_err.c_str(); }
+
+int modgpu_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off, int device,
+                        void *hip_stream)
+{
+    int rc = select_device(device);
+    if (rc) return rc;
+    return cycle_device_impl(dev_buf, n, key, stream_off, static_cast<hipStream_t>(hip_stream));
+}
+
+int modgpu_cycle_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, int device)
+{
+    return cycle_host_impl(host_buf, n, key, stream_off, device);
+}
+
+int modgpu_hdr_decrypt_host(uint8_t *hdr, uint64_t size, int device)
+{
+    if (!hdr || size < 4) return fail(MODGPU_ERR_INVALID, "header shorter than its magic");
+    uint32_t magic = load_le32(hdr);
+    if (magic != MODGPU_MAGIC_PS3 && magic != MODGPU_MAGIC_PS4)
+        return fail(MODGPU_ERR_MAGIC, "unknown header magic");
+    uint32_t key = magic == MODGPU_MAGIC_PS3 ? MODGPU_KEY_PS3 : MODGPU_KEY_PS4;
+    return cycle_host_impl(hdr + 4, size - 4, (int32_t)key, 0, device);
+}
+
+int modgpu_hdr_encrypt_host(uint8_t *hdr, uint64_t size, int ps4, int device)
+{
+    if (!hdr || size < 4) return fail(MODGPU_ERR_INVALID, "header shorter than its magic");
+    // cipher first: on failure the caller's buffer is left as it was
+    int rc = cycle_host_impl(hdr + 4, size - 4, (int32_t)(ps4 ? MODGPU_KEY_PS4 : MODGPU_KEY_PS3), 0, device);
+    if (rc) return rc;
+    store_le32(hdr, ps4 ? MODGPU_MAGIC_PS4 : MODGPU_MAGIC_PS3);
+    return MODGPU_OK;
+}
+
+int modgpu_cycle_parts_host(uint8_t *const *parts, const uint64_t *sizes, int n_parts, int32_t key,
+                            int n_devices)
+{
+    if (n_parts < 0 || (n_parts > 0 && (!parts || !sizes))) return fail(MODGPU_ERR_INVALID, "bad part list");
+    int avail = device_count_raw();
+    if (avail <= 0) return fail(MODGPU_ERR_NO_DEVICE, "no HIP device visible");
+    if (n_devices <= 0 || n_devices > avail) n_devices = avail;
+    n_devices = std::min(n_devices, std::max(n_parts, 1));
+    std::vector<int> rcs(n_devices, MODGPU_OK);
+    std::vector<std::string> errs(n_devices);
+    std::vector<std::thread> workers;
+    for (int d = 0; d < n_devices; ++d) {
+        workers.emplace_back([&, d] {
+            for (int i = d; i < n_parts; i += n_devices) { // part i -> GPU i mod N
+                int rc = cycle_host_impl(parts[i], sizes[i], key, 0, d);
+                if (rc) {
+                    rcs[d] = rc;
+                    errs[d] = t_err;
+                    return;
+                }
+            }
+        });
+    }
+    for (auto &w : workers) w.join();
+    for (int d = 0; d < n_devices; ++d)
+        if (rcs[d]) {
+            t_err = errs[d];
+            return rcs[d];
+        }
+    return MODGPU_OK;
+}
+
+int modgpu_alloc(void **dev_ptr, uint64_t n, int device)
+{
+    if (!dev_ptr) return fail(MODGPU_ERR_INVALID, "null out pointer");
+    int rc = select_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipMalloc(dev_ptr, n ? n : 1));
+    return MODGPU_OK;
+}
+
+int modgpu_free(void *dev_ptr, int device)
+{
+    int rc = select_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipFree(dev_ptr));
+    return MODGPU_OK;
+}
+
+int modgpu_h2d(void *dev_dst, const void *host_src, uint64_t n, int device)
+{
+    int rc = select_device(device);
+    if (rc) return rc;
+    if (n) HIP_TRY(hipMemcpy(dev_dst, host_src, n, hipMemcpyHostToDevice));
+    return MODGPU_OK;
+}
+
+int modgpu_d2h(void *host_dst, const void *dev_src, uint64_t n, int device)
+{
+    int rc = select_device(device);
+    if (rc) return rc;
+    if (n) HIP_TRY(hipMemcpy(host_dst, dev_src, n, hipMemcpyDeviceToHost));
+    return MODGPU_OK;
+}
+
+int modgpu_sync(int device, void *hip_stream)
+{
+    int rc = select_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
+    return MODGPU_OK;
+}
+
+int modgpu_time_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off, int device,
+                             void *hip_stream, int iters, float *ms_per_launch)
+{
+    if (iters <= 0 || !ms_per_launch) return fail(MODGPU_ERR_INVALID, "bad timing arguments");
+    int rc = select_device(device);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int i = 0; i < iters && rc == MODGPU_OK; ++i) rc = cycle_device_impl(dev_buf, n, key, stream_off, st);
+    hipError_t e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail_hip(e, "event timing");
+    *ms_per_launch = ms / (float)iters;
+    return MODGPU_OK;
+}
+
+uint32_t modgpu_state_at(int32_t key, uint64_t i)
+{
+    uint32_t r = lcg::state_residue(lcg::key_residue(key), i);
+    return r ? r : lcg::M; // the reference shows residue 0 as m (CEncryptionCycler.cpp:19-22)
+}
+
+int modgpu_jump_table(int which, uint32_t *out, int count)
+{
+    if (!out || count < 0) return 0;
+    const uint32_t *src = nullptr;
+    int n = 0;
+    switch (which) {
+    case 0: src = lcg::kBytePow.v; n = 16; break;
+    case 1: src = lcg::kLanePow.v; n = 256; break;
+    case 2: src = lcg::kTileLo.v; n = 256; break;
+    case 3: src = lcg::kTileHi.v; n = 256; break;
+    default: return 0;
+    }
+    n = std::min(n, count);
+    std::memcpy(out, src, (size_t)n * sizeof(uint32_t));
+    return n;
+}
+
+} // extern "C"
