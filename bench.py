@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its config 2/3 workload.
+
+A "step" is one encrypt pass + one decrypt pass of the cipher hot path
+(CEncryptionCycler::Cycle, Modulate/CEncryptionCycler.cpp:4-25) over one synthetic 4 GiB
+(2^32-byte) .ark part that is already resident in HBM: two kernel launches through the C ABI
+(modgpu_cycle_device).  With N GPUs every rank owns one such part (parts are independent
+streams: no collective on the data path, weak scaling).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` = part bytes cycled per second summed over all ranks
+(each pass over a byte counts once; HBM traffic is twice that: 1 read + 1 write per byte).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def cpu_baseline(sample_bytes):
+    """The reference's single-thread loop on this node's host cores, timed on a bounded sample
+    (encrypt + decrypt of `sample_bytes`).  Uses the compiled reference (oracle/_ref) when its
+    prebuilt library travelled with the repo, else our C restatement of it (the oracle)."""
+    from oracle import oracle as O
+    buf = O.splitmix_bytes(sample_bytes, 7)
+    kind = "reference" if O.have_ref() else "port"
+    fn = O.ref_cycle if kind == "reference" else O.cycle
+    fn(buf[:1 << 16].copy(), O.KEY_PS4)  # load + warm
+    t0 = time.perf_counter()
+    fn(buf, O.KEY_PS4)
+    fn(buf, O.KEY_PS4)
+    dt = time.perf_counter() - t0
+    return {"value": round(2 * sample_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
+            "sample": f"{sample_bytes >> 20} MiB part, encrypt+decrypt (2 passes), 1 thread, {dt:.1f} s; "
+                      f"host has {os.cpu_count()} logical cores"}
+
+
+def load_traffic(n_bytes):
+    """HBM bytes per launch from the committed PMC summary (profiles/), if one exists for this size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as f:
+            s = json.load(f)
+        if int(s.get("part_bytes", -1)) == n_bytes:
+            return s.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--part-bytes", type=int, default=1 << 32, help="bytes per .ark part (default 4 GiB)")
+    ap.add_argument("--key", type=lambda s: int(s, 0), default=0x90CFC0AB)
+    ap.add_argument("--cpu-sample-bytes", type=int, default=1 << 30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import modulate_amd as M
+    from modulate_amd import sharding
+
+    rank, local_rank, world = sharding.dist_env()
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        a.gpus = world
+    dist = None
+    red_dev = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        red_dev = torch.device("cuda", local_rank)
+    if M.device_count() < 1:
+        raise SystemExit("no HIP device: bench.py measures the HIP path only")
+    dev = local_rank
+
+    n = a.part_bytes
+    # synthetic part: uniform random bytes (values do not affect timing; they make the checks real)
+    rng = np.random.default_rng(0x4D6F6475 + rank)
+    tile = rng.integers(0, 256, size=min(n, 64 << 20), dtype=np.uint8)
+    part = M.DeviceBuffer(n, device=dev)
+    for off in range(0, n, tile.size):
+        part.upload(tile[:min(tile.size, n - off)], offset=off)
+
+    def barrier():
+        part.sync()
+        if dist is not None:
+            dist.barrier()
+            part.sync()
+
+    # warmup
+    for _ in range(a.warmup):
+        part.cycle(a.key)
+        part.cycle(a.key)
+    barrier()
+    # timed region: exactly `steps` steps = 2*steps launches, HIP events on the launch stream
+    t0 = time.perf_counter()
+    ms_per_launch = M.time_cycle_device(part.ptr, n, a.key, 0, dev, None, iters=2 * a.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    dt = sharding.max_over_ranks(dt, red_dev)
+    ms_per_launch = sharding.max_over_ranks(ms_per_launch, red_dev)
+
+    # post-run checks (outside the timed region): even pass count => original bytes; one more
+    # pass => oracle ciphertext on sampled windows.
+    from oracle import oracle as O
+    ok = bool(np.array_equal(part.download(1 << 20, offset=0), tile[:1 << 20]))
+    part.cycle(a.key)
+    part.sync()
+    for off in (0, (n // 2) - 4096 if n >= 8192 else 0, max(0, n - (1 << 16))):
+        ln = min(1 << 16, n - off)
+        pt = np.resize(np.roll(tile, -(off % tile.size)), ln) if ln <= tile.size else None
+        ct = part.download(ln, offset=off)
+        ok = ok and bool(np.array_equal(ct ^ pt, O.keystream(a.key, ln, off)))
+    part.cycle(a.key)
+    part.sync()
+    n_ok = sharding.sum_over_ranks(1.0 if ok else 0.0, red_dev)
+
+    if rank == 0:
+        total_bytes = float(world) * a.steps * 2 * n
+        achieved = 2.0 * n / (ms_per_launch * 1e-3) / 1e9  # read + write per launch
+        traffic = load_traffic(n)
+        out = {
+            "metric": "GB/s encrypt+decrypt over synthetic .ark parts",
+            "value": round(total_bytes / dt / 1e9, 2),
+            "unit": "GB/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"config {'2' if world == 1 else '3'}: {world} x {n} B synthetic .ark part"
+                                   f"{'s, one per GPU' if world > 1 else ''}, encrypt pass + decrypt pass per step, "
+                                   f"HBM-resident, key {a.key:#010x}",
+                       "part_bytes": n, "passes_per_step": 2, "parallelism": f"parts{world}",
+                       "value_counts": "payload bytes cycled per second (HBM read+write traffic is 2x)",
+                       "bit_exact_check": "pass" if n_ok == world else "FAIL"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "modgpu_cycle_kernel<4>", "ms_per_launch": round(ms_per_launch, 4),
+                         "algorithmic_bytes_per_launch": 2 * n},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_sample_bytes)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    part.free()
+    if n_ok != world:
+        raise SystemExit("bit-exact check FAILED")
+
+
+if __name__ == "__main__":
+    main()
