@@ -9,7 +9,7 @@ struct CycleArgs {
     void *body;          // 16-byte aligned start of the body
     uint64_t body_words; // full 16-byte words in the body
     uint32_t base_body;  // state of the body's first byte
-    uint32_t stride_mul; // a^(4096 * U * gridDim): advances a lane-word by one grid trip
+    uint32_t stride_mul; // a^(chunk_bytes * gridDim): advances a lane-word by one grid trip
     uint8_t *head_ptr;   // first byte of the buffer (head_n < 16 bytes before the body)
     uint8_t *tail_ptr;   // first byte after the body (tail_n < 16 bytes)
     uint32_t head_n, tail_n;
@@ -17,5 +17,13 @@ struct CycleArgs {
     uint32_t base_tail;  // state of the first tail byte
 };
 
-// grid * unroll must be <= 65536 (two-level tile table).  Returns hipGetLastError().
-hipError_t modgpu_launch_cycle(const CycleArgs &a, int unroll, uint32_t grid, hipStream_t stream);
+// Launch shapes.  A workgroup trip covers `chunk_bytes` contiguous bytes; the grid strides over
+// chunks.  grid * chunk_bytes / 4096 must stay <= 65536 (two-level tile jump table).
+enum CycleVariant : int {
+    CYCLE_SMALL = 0, // 256 threads x 1 word : 4 KiB chunks, headers and other small buffers
+    CYCLE_LARGE = 1, // 1024 threads x 4 words, software-pipelined: 64 KiB chunks, streaming parts
+};
+uint32_t modgpu_variant_chunk_bytes(int variant);
+
+// Returns hipGetLastError().
+hipError_t modgpu_launch_cycle(const CycleArgs &a, int variant, uint32_t grid, hipStream_t stream);

@@ -1,0 +1,204 @@
+// cycle_kernel_impl.h -- device code of the cycle kernel (see cycle_kernel.hip for the design
+// notes).  Kept in a header so tools/tune_cycle.hip can instantiate and time exactly the code the
+// product ships, next to copy-only / compute-only ablations of it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "lcg.h"
+#include "cycle_kernel.h"
+
+namespace {
+
+using u32x4 = uint32_t __attribute__((ext_vector_type(4))); // one dwordx4 lane-word
+
+// Jump tables, baked into the code object (see lcg.h).  kTile* are read with wave-uniform
+// indices; kLanePow once per thread at start-up.
+__constant__ lcg::Table<256> c_lane_pow = lcg::kLanePow;
+__constant__ lcg::Table<256> c_tile_lo = lcg::kTileLo;
+__constant__ lcg::Table<256> c_tile_hi = lcg::kTileHi;
+
+// Mersenne fold of the 64-bit product s * (2*y):  p2 = hi * 2^32 + 2 * lo31  with
+// hi = floor(s*y / 2^31), lo31 = s*y mod 2^31, so  s*y == hi + lo31 (mod m).
+// One more multiply-add does the shift and the add together:
+//     lo2 * (2^31 - 1) + p2  =  lo31 * 2^32 - lo2 + hi * 2^32 + lo2  =  (hi + lo31) * 2^32
+// i.e. v_mad_u64_u32 {0, X} = p2.lo * m + p2, whose high dword is X = hi + lo31  (< 2^32).
+__device__ __forceinline__ uint32_t mul_fold(uint32_t s, uint32_t y2)
+{
+    uint64_t p2 = (uint64_t)s * y2;
+    uint64_t q = (uint64_t)(uint32_t)p2 * lcg::M + p2;
+    return (uint32_t)(q >> 32);
+}
+
+// x canonical residue (< 2^31), y any residue < 2^31.  Returns x*y mod m, canonical.
+// X = x*y mod m or that + m, never m itself (m is prime, inputs non-zero), so min(X, X - m)
+// with unsigned wrap picks the canonical one.
+__device__ __forceinline__ uint32_t mulmod_canon(uint32_t x, uint32_t y)
+{
+    uint32_t X = mul_fold(x, 2u * y);
+    return min(X, X - lcg::M);
+}
+
+// ---- keystream bytes of one dword --------------------------------------------------------
+// ALG 0: plain C; the compiler packs the four low bytes with shifts / v_perm.
+// ALG 1: canonicalise and pack in one SDWA add per byte: byte J of `w` := low8(X + (X >> 31)).
+template <int SEL> __device__ __forceinline__ void put_byte(uint32_t &w, uint32_t X)
+{
+    uint32_t c = X >> 31; // the only possible excess over the canonical residue is m: +1 mod 256
+    if constexpr (SEL == 0)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(X), "v"(c));
+    else if constexpr (SEL == 1)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(X), "v"(c));
+    else if constexpr (SEL == 2)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(X), "v"(c));
+    else
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(X), "v"(c));
+}
+
+template <int J> __device__ __forceinline__ uint32_t state_x(uint32_t s)
+{
+    return mul_fold(s, 2u * lcg::kBytePow.v[J]); // non-canonical state of byte J of the word
+}
+
+// Low bytes of the canonical states of bytes J0..J0+3 of the word whose first byte has
+// canonical state s, packed little-endian.
+template <int J0, int ALG> __device__ __forceinline__ uint32_t ks_state_dword(uint32_t s)
+{
+    if constexpr (ALG == 0) {
+        auto lowbyte = [](uint32_t X) { return (X + (X >> 31)) & 0xFFu; };
+        uint32_t b0 = (J0 == 0) ? (s & 0xFFu) : lowbyte(state_x<(J0 == 0 ? 1 : J0)>(s));
+        return b0 | (lowbyte(state_x<J0 + 1>(s)) << 8) | (lowbyte(state_x<J0 + 2>(s)) << 16) |
+               (lowbyte(state_x<J0 + 3>(s)) << 24);
+    } else {
+        uint32_t w = s; // byte 0 of the first dword is the state itself; bytes 1..3 get overwritten
+        if constexpr (J0 != 0) put_byte<0>(w, state_x<(J0 == 0 ? 1 : J0)>(s));
+        put_byte<1>(w, state_x<J0 + 1>(s));
+        put_byte<2>(w, state_x<J0 + 2>(s));
+        put_byte<3>(w, state_x<J0 + 3>(s));
+        return w;
+    }
+}
+
+// data ^ keystream for one 16-byte word whose first byte has state s.
+// keystream = ~state_bytes  =>  data ^ ks = ~(data ^ state_bytes)  (one v_xnor per dword).
+template <int ALG> __device__ __forceinline__ u32x4 cycle_word(u32x4 d, uint32_t s)
+{
+    d.x = ~(d.x ^ ks_state_dword<0, ALG>(s));
+    d.y = ~(d.y ^ ks_state_dword<4, ALG>(s));
+    d.z = ~(d.z ^ ks_state_dword<8, ALG>(s));
+    d.w = ~(d.w ^ ks_state_dword<12, ALG>(s));
+    return d;
+}
+
+// One byte at state s (head / tail bytes outside the aligned body).
+__device__ __forceinline__ uint8_t cycle_byte(uint8_t d, uint32_t s) { return (uint8_t)~(d ^ (uint8_t)s); }
+
+enum : int { MODE_FULL = 0, MODE_COPY = 1, MODE_COMPUTE = 2 };
+constexpr int AUX_NT = 2; // buffer cache-policy bit: non-temporal (streaming)
+
+} // namespace
+
+// U     = lane-words per thread per trip (independent 16-byte loads in flight per lane)
+// BLOCK = threads per workgroup; one workgroup trip covers U*BLOCK*16 contiguous bytes
+// ALG   = keystream instruction sequence (see ks_state_dword)
+// PIPE  = software pipeline: the next trip's loads are issued before this trip's arithmetic
+// MODE  = MODE_FULL in the product; the other two are timing ablations for tools/tune_cycle
+//
+// Addressing is buffer_load/store_dwordx4 through a per-trip descriptor built from scalars:
+// no per-lane 64-bit pointer arithmetic in the loop, and the hardware range check (num_records =
+// bytes left in the body, capped at the chunk) drops the lanes past the end of a ragged last
+// chunk -- there is no tail branch.
+template <int U, int BLOCK, int ALG, bool PIPE, int MODE>
+__global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
+{
+    static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
+    constexpr uint32_t CHUNK = (uint32_t)U * BLOCK * lcg::WORD; // bytes per workgroup trip
+    constexpr uint32_t SUB = BLOCK * lcg::WORD;                 // bytes per sub-step (one load per lane)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t blk = blockIdx.x;
+
+    // ---- ragged edges: < 16 bytes before / after the aligned body, done bytewise by block 0
+    if (blk == 0 && tid < 32) {
+        if (tid < a.head_n) {
+            uint32_t s = a.base_head;
+            for (uint32_t j = 0; j < tid; ++j) s = mulmod_canon(s, lcg::A);
+            a.head_ptr[tid] = cycle_byte(a.head_ptr[tid], s);
+        } else if (tid >= 16 && tid - 16 < a.tail_n) {
+            uint32_t t = tid - 16;
+            uint32_t s = a.base_tail;
+            for (uint32_t j = 0; j < t; ++j) s = mulmod_canon(s, lcg::A);
+            a.tail_ptr[t] = cycle_byte(a.tail_ptr[t], s);
+        }
+    }
+
+    // ---- aligned body, chunk c = blk, blk + G, blk + 2G, ...
+    const uint64_t body_bytes = a.body_words * lcg::WORD;
+    const uint64_t step = (uint64_t)gridDim.x * CHUNK;
+    uint64_t off = (uint64_t)blk * CHUNK;
+    if (off >= body_bytes) return; // uniform for the workgroup
+
+    // jump to this lane's first word: base * a^(4096*tile) * a^(16*(tid%256)),
+    // tile = blk*U*(BLOCK/256) + tid/256 < 65536 (host: grid * U * BLOCK/256 <= 65536)
+    const uint32_t tile = blk * (U * (BLOCK / 256)) + (tid >> 8);
+    uint32_t s[U];
+    s[0] = mulmod_canon(a.base_body, c_tile_hi.v[(tile >> 8) & 255]);
+    s[0] = mulmod_canon(s[0], c_tile_lo.v[tile & 255]);
+    s[0] = mulmod_canon(s[0], c_lane_pow.v[tid & 255]);
+#pragma unroll
+    for (int u = 1; u < U; ++u) s[u] = mulmod_canon(s[u - 1], lcg::kTileLo.v[BLOCK / 256]);
+
+    uint8_t *const body = static_cast<uint8_t *>(a.body);
+    const uint32_t voff = tid * lcg::WORD;
+    auto rsrc_at = [&](uint64_t o) {
+        uint64_t left = o < body_bytes ? body_bytes - o : 0;
+        return __builtin_amdgcn_make_buffer_rsrc(body + o, 0, (int)(left < CHUNK ? left : CHUNK), 0x00020000);
+    };
+    auto load = [&](u32x4(&d)[U], uint64_t o) {
+        auto r = rsrc_at(o);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (MODE == MODE_COMPUTE) d[u] = u32x4{tid, blk, (uint32_t)o, (uint32_t)u};
+            else d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, AUX_NT);
+        }
+    };
+    auto process_store = [&](u32x4(&d)[U], uint64_t o) {
+        auto r = rsrc_at(o);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (MODE == MODE_COPY) d[u] = ~d[u];
+            else {
+                d[u] = cycle_word<ALG>(d[u], s[u]);
+                s[u] = mulmod_canon(s[u], a.stride_mul);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (MODE == MODE_COMPUTE) {
+                if ((d[u].x ^ d[u].y ^ d[u].z ^ d[u].w) == 0x9E3779B9u && s[u] == 1u)
+                    __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, AUX_NT);
+            } else __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, AUX_NT);
+        }
+    };
+
+    if constexpr (!PIPE) {
+        for (; off < body_bytes; off += step) {
+            u32x4 d[U];
+            load(d, off);
+            process_store(d, off);
+        }
+    } else {
+        // ping-pong: chunk k+1 is in flight while chunk k is computed and stored.  A chunk past
+        // the end has a zero-size descriptor: its loads return 0 and its stores are dropped.
+        u32x4 d0[U], d1[U];
+        load(d0, off);
+        while (true) {
+            load(d1, off + step);
+            process_store(d0, off);
+            off += step;
+            if (off >= body_bytes) break;
+            load(d0, off + step);
+            process_store(d1, off);
+            off += step;
+            if (off >= body_bytes) break;
+        }
+    }
+}

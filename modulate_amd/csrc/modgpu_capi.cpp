@@ -74,11 +74,13 @@ int resolve_device(int device, int *out)
 
 struct Plan {
     CycleArgs args;
-    int unroll;
+    int variant;
     uint32_t grid;
 };
 
-constexpr uint32_t kMaxGrid = 256u * 8u; // 256 CUs x 8 resident 256-thread blocks
+constexpr uint32_t kLargeGrid = 512u;        // two 1024-thread workgroups per CU (8 waves/SIMD), persistent
+constexpr uint32_t kSmallGridMax = 16384u;   // 4 KiB chunks: grid * 1 tile <= 65536
+constexpr uint64_t kLargeMin = 8ull << 20;   // below this a one-shot small-chunk grid is used
 
 // Splits [buf, buf+n) into <16 head bytes, an aligned body of 16-byte words and <16 tail bytes,
 // and computes the states that seed each piece.  key_res != 0.
@@ -103,14 +105,14 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
     a.base_body = lcg::state_residue(key_res, o + head);
     a.base_tail = lcg::state_residue(key_res, o + head + (words * 16) % lcg::PERIOD);
 
-    // words per block-trip = 256 * unroll.  Small bodies: one word per thread, enough blocks to
-    // cover it; large: 4 words per thread per trip and a grid that fills the chip 8 deep.
-    uint64_t tiles = (words + lcg::BLOCK - 1) / lcg::BLOCK;
-    p.unroll = tiles >= 4ull * kMaxGrid ? 4 : (tiles >= 2ull * kMaxGrid ? 2 : 1);
-    uint64_t blocks = (tiles + p.unroll - 1) / p.unroll;
-    p.grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, kMaxGrid));
-    // one grid trip advances every lane-word by grid*unroll tiles of 4096 bytes
-    a.stride_mul = lcg::powmod(lcg::A, ((uint64_t)p.grid * p.unroll * lcg::TILE) % lcg::PERIOD);
+    uint64_t body_bytes = words * 16;
+    p.variant = body_bytes >= kLargeMin ? CYCLE_LARGE : CYCLE_SMALL;
+    uint64_t chunk = modgpu_variant_chunk_bytes(p.variant);
+    uint64_t chunks = (body_bytes + chunk - 1) / chunk;
+    uint64_t cap = p.variant == CYCLE_LARGE ? kLargeGrid : kSmallGridMax;
+    p.grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(chunks, cap));
+    // one grid trip advances every lane-word by grid chunks
+    a.stride_mul = lcg::powmod(lcg::A, ((uint64_t)p.grid * chunk) % lcg::PERIOD);
     return p;
 }
 
@@ -121,7 +123,7 @@ int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_of
     uint32_t key_res = lcg::key_residue(key);
     if (key_res == 0) return MODGPU_OK; // keystream is all zero (state sticks at m): identity
     Plan p = plan_cycle(dev_buf, n, key_res, stream_off);
-    hipError_t e = modgpu_launch_cycle(p.args, p.unroll, p.grid, stream);
+    hipError_t e = modgpu_launch_cycle(p.args, p.variant, p.grid, stream);
     if (e != hipSuccess) return fail_hip(e, "cycle kernel launch");
     return MODGPU_OK;
 }

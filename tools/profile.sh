@@ -1,0 +1,19 @@
+#!/bin/bash
+# tools/profile.sh <tag> -- run on the GPU box (via gpurun) from the repo root.  Collects, for the
+# default bench.py command, (1) the rocprofv3 kernel-trace + stats summary and (2) the HBM traffic
+# counters in two separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass;
+# MI355X_MICROARCH.md "rocprofv3 PMC slots"), into gpurun_out/prof_<tag>/.  Summaries are then
+# distilled by tools/summarize_profile.py into profiles/.
+set -e
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/bench_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $BENCH > $OUT/bench_sq.log 2>&1 || true
+find $OUT -name "*.csv" | head -50 > $OUT/files.txt
+python3 tools/summarize_profile.py $OUT $TAG > $OUT/summary.log 2>&1 || true
+cat $OUT/summary.log

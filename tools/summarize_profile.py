@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Distil rocprofv3 CSV output (tools/profile.sh) into small, committable summaries:
+   <out>/<tag>_kernel_stats.csv   per-kernel count / total / average duration
+   <out>/<tag>_pmc_summary.json   FETCH_SIZE / WRITE_SIZE per launch of the cycle kernel,
+                                  corrected as MI355X_MICROARCH.md (HBM) prescribes."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(root, pat):
+    return sorted(glob.glob(os.path.join(root, "**", pat), recursive=True))
+
+
+def main():
+    root, tag = sys.argv[1], sys.argv[2]
+    out = {"tag": tag}
+    # ---- kernel trace
+    per = defaultdict(list)
+    for f in find(os.path.join(root, "trace"), "*kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            per[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    rows = []
+    for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+        rows.append({"kernel": k, "calls": len(v), "total_ns": sum(v), "avg_ns": sum(v) / len(v), "min_ns": min(v), "max_ns": max(v)})
+    with open(os.path.join(root, f"{tag}_kernel_stats.csv"), "w") as f:
+        w = csv.DictWriter(f, fieldnames=["kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns"])
+        w.writeheader()
+        w.writerows(rows)
+    for r in rows[:5]:
+        print(f"{r['calls']:6d} x avg {r['avg_ns']/1e3:10.1f} us  {r['kernel'][:90]}")
+    cyc = [r for r in rows if "modgpu_cycle_kernel" in r["kernel"]]
+    if cyc:
+        out["cycle_kernel"] = cyc[0]["kernel"]
+        out["avg_launch_ns_traced"] = cyc[0]["avg_ns"]
+    # ---- counters
+    def counter(dirname, name):
+        vals = defaultdict(float)
+        for f in find(os.path.join(root, dirname), "*counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                if "modgpu_cycle_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name:
+                    vals[(r["Dispatch_Id"])] += float(r["Counter_Value"])
+        return list(vals.values())
+    fetch = counter("pmc_fetch", "FETCH_SIZE")
+    write = counter("pmc_write", "WRITE_SIZE")
+    if fetch and write:
+        # keep the 4 GiB launches only (largest values), take the median
+        fetch.sort(); write.sort()
+        f_kb, w_kb = fetch[len(fetch) // 2], write[len(write) // 2]
+        # MI355X_MICROARCH.md HBM: counters are in KiB... FETCH_SIZE reads 1/2 of a wide coalesced
+        # 16 B/lane stream on gfx950 -> double it; WRITE_SIZE is exact for 16 B/lane stores.
+        out.update({"FETCH_SIZE_kb_median": f_kb, "WRITE_SIZE_kb_median": w_kb,
+                    "fetch_bytes_corrected": 2 * f_kb * 1024, "write_bytes": w_kb * 1024,
+                    "hbm_bytes_per_launch": 2 * f_kb * 1024 + w_kb * 1024,
+                    "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as is; KiB units"})
+    sq = {}
+    for name in ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"):
+        v = counter("pmc_sq", name)
+        if v:
+            v.sort()
+            sq[name] = v[len(v) // 2]
+    if sq:
+        out["sq_median_per_launch"] = sq
+    with open(os.path.join(root, f"{tag}_pmc_summary.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

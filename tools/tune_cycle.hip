@@ -1,0 +1,98 @@
+// tools/tune_cycle.hip -- interleaved A/B timing of the cycle kernel's variants on one device:
+// workgroup size, lane-words in flight, keystream instruction sequence, software pipelining,
+// grid size, and the copy-only / compute-only ablations that bound it from the memory and the
+// VALU side.  Instantiates the product's own device code (modulate_amd/csrc/cycle_kernel_impl.h).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Imodulate_amd/csrc tools/tune_cycle.hip -o tools/tune_cycle
+// Run:   tools/tune_cycle [bytes=4294967296] [rounds=5]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "cycle_kernel_impl.h"
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+struct Variant {
+    std::string name;
+    void (*launch)(const CycleArgs &, uint32_t grid, hipStream_t);
+    uint64_t chunk;
+    uint32_t grid;
+    std::vector<float> ms;
+};
+
+template <int U, int BLOCK, int ALG, bool PIPE, int MODE> void launch(const CycleArgs &a, uint32_t grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((modgpu_cycle_kernel<U, BLOCK, ALG, PIPE, MODE>), dim3(grid), dim3(BLOCK), 0, st, a);
+}
+
+int main(int argc, char **argv)
+{
+    uint64_t n = argc > 1 ? strtoull(argv[1], nullptr, 0) : (1ull << 32);
+    int rounds = argc > 2 ? atoi(argv[2]) : 5;
+    uint8_t *buf;
+    CHECK(hipMalloc(&buf, n));
+    CHECK(hipMemset(buf, 0x5A, n));
+    hipStream_t st;
+    CHECK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+
+    std::vector<Variant> vs;
+#define ADD(U, B, ALG, PIPE, MODE, g)                                                                        \
+    do {                                                                                                     \
+        char b_[128];                                                                                        \
+        snprintf(b_, sizeof b_, "%-7s U=%d B=%4d alg=%d pipe=%d grid=%5u", MODE == MODE_FULL ? "full" : MODE == MODE_COPY ? "copy" : "compute", U, B, ALG, (int)PIPE, (unsigned)(g)); \
+        vs.push_back({b_, launch<U, B, ALG, PIPE, MODE>, (uint64_t)U * B * 16, (g), {}});                     \
+    } while (0)
+    for (uint32_t g : {256u, 512u, 1024u}) {
+        ADD(4, 1024, 0, false, MODE_FULL, g);
+        ADD(4, 1024, 1, false, MODE_FULL, g);
+        ADD(4, 1024, 0, true, MODE_FULL, g);
+        ADD(4, 1024, 1, true, MODE_FULL, g);
+        ADD(2, 1024, 1, true, MODE_FULL, g);
+        ADD(8, 1024, 1, false, MODE_FULL, g);
+        ADD(8, 512, 1, true, MODE_FULL, g);
+        ADD(4, 512, 1, true, MODE_FULL, g);
+        ADD(4, 256, 1, true, MODE_FULL, g);
+        ADD(4, 256, 1, false, MODE_FULL, g);
+        ADD(4, 1024, 1, false, MODE_COPY, g);
+        ADD(4, 1024, 1, true, MODE_COPY, g);
+        ADD(4, 1024, 0, false, MODE_COMPUTE, g);
+        ADD(4, 1024, 1, false, MODE_COMPUTE, g);
+    }
+    ADD(4, 256, 1, false, MODE_FULL, 2048u);
+    ADD(4, 256, 0, false, MODE_FULL, 2048u);
+    ADD(4, 256, 1, true, MODE_FULL, 2048u);
+    ADD(1, 256, 1, false, MODE_FULL, 16384u);
+
+    CycleArgs a{};
+    a.head_ptr = buf; a.head_n = 0; a.body = buf; a.body_words = n / 16; a.tail_ptr = buf + n; a.tail_n = 0;
+    a.base_head = a.base_body = a.base_tail = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
+
+    for (int r = 0; r < rounds + 1; ++r) {
+        for (auto &v : vs) {
+            a.stride_mul = lcg::powmod(lcg::A, ((uint64_t)v.grid * v.chunk) % lcg::PERIOD);
+            CHECK(hipEventRecord(e0, st));
+            v.launch(a, v.grid, st);
+            v.launch(a, v.grid, st);
+            CHECK(hipEventRecord(e1, st));
+            CHECK(hipEventSynchronize(e1));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0) v.ms.push_back(ms / 2);
+        }
+    }
+    CHECK(hipGetLastError());
+    printf("bytes=%llu rounds=%d  (GB/s = read+write = 2*bytes/t)\n", (unsigned long long)n, rounds);
+    for (auto &v : vs) {
+        std::sort(v.ms.begin(), v.ms.end());
+        float med = v.ms[v.ms.size() / 2], mn = v.ms.front();
+        printf("%s  med %.4f ms  min %.4f ms  -> %7.1f GB/s (med) %7.1f (best)\n", v.name.c_str(), med, mn,
+               2.0 * n / med / 1e6, 2.0 * n / mn / 1e6);
+    }
+    return 0;
+}
