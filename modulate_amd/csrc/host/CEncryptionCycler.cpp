@@ -1,0 +1,27 @@
+// CEncryptionCycler.cpp -- the whole binding between the reference's cipher seam and the HIP
+// layer: one call into include/modgpu.h.  Replaces Modulate/CEncryptionCycler.cpp:4-25.
+#include "CEncryptionCycler.h"
+
+#include <stdexcept>
+#include <string>
+
+#include "../../../include/modgpu.h"
+
+namespace {
+thread_local int t_device = -1;
+}
+
+void CEncryptionCycler::SetDevice( int liDevice ) { t_device = liDevice; }
+int CEncryptionCycler::GetDevice() { return t_device; }
+
+void CEncryptionCycler::Cycle( unsigned char* lpData, unsigned int liDataSize, int liInitialKey )
+{
+    // stream offset 0: every Cycle call restarts the keystream (CEncryptionCycler.cpp:7)
+    const int liStatus = modgpu_cycle_host( lpData, liDataSize, liInitialKey, 0, t_device );
+    if( liStatus != MODGPU_OK )
+    {
+        // The reference's Cycle returns void and cannot fail; failing silently (or quietly
+        // computing on the CPU) would hide a broken GPU path, so fail loudly instead.
+        throw std::runtime_error( std::string( "CEncryptionCycler::Cycle: GPU path failed: " ) + modgpu_last_error() );
+    }
+}

@@ -1,0 +1,23 @@
+// CEncryptionCycler.h -- drop-in for Modulate/CEncryptionCycler.h:3-10.
+//
+// Same class name, same public signature, stateless and default-constructible, so the
+// reference's three callers compile against it unchanged:
+//     CArk::Load        Modulate/CArk.cpp:338-339
+//     CArk::SaveArk     Modulate/CArk.cpp:1135-1136
+//     Decode            Modulate/Modulate.cpp:485-486
+// The reference's private CycleKey helper is gone: the step lives in the gfx950 kernel
+// (modulate_amd/csrc/cycle_kernel_impl.h) behind the C ABI of include/modgpu.h.
+#pragma once
+
+class CEncryptionCycler
+{
+public:
+    // In-place LCG-XOR of liDataSize bytes at lpData (a HOST pointer, any alignment), keystream
+    // restarted from liInitialKey -- bit-identical to the reference loop, computed on the MI355X.
+    // Throws std::runtime_error if the GPU path fails: there is no CPU loop to fall back to.
+    void Cycle( unsigned char* lpData, unsigned int liDataSize, int liInitialKey );
+
+    // Which GPU the calling thread's Cycle calls use (-1 = that thread's current HIP device).
+    static void SetDevice( int liDevice );
+    static int GetDevice();
+};

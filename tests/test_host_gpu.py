@@ -1,0 +1,175 @@
+"""GPU tests of the C++ host mirror: the reference's own seam (CEncryptionCycler::Cycle), the
+three framed call sites (Load / SaveArk / Decode), and the pack -> unpack -> repack round trips of
+BASELINE configs 4 and 5 (scaled to test size), all against the CPU oracle / the Python header
+restatement."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import ark_header as AH
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "modulate_amd", "bin", "modulate")
+
+
+@pytest.fixture(scope="module")
+def host(modgpu):
+    assert modgpu.device_count() >= 1
+    from modulate_amd import host as H
+    H.lib()
+    H.set_flags(overwrite=True, ignore_new=True, pack_all=False, verbose=False)
+    H.select_platform(True)
+    return H
+
+
+def synth(n, seed, max_size=3000):
+    rng = np.random.default_rng(seed)
+    names = [f"dir{k % 97}/sub{k % 13}/f{k}.bin" for k in range(n)]
+    sizes = [int(x) for x in rng.integers(0, max_size, size=n)]
+    data = rng.integers(0, 256, size=sum(sizes), dtype=np.uint8)
+    return names, sizes, data
+
+
+def test_cycle_via_reference_class_signature(host, oracle):
+    """CEncryptionCycler().Cycle(buf+4, size-4, key): the exact call shape of the 3 reference sites."""
+    for key in (0x90CFC0AB, 0xC64EED30, 1, 0xFFFFFFFF, 0, 0x7FFFFFFF):
+        for n in (0, 1, 15, 4092, 100_001):
+            whole = oracle.splitmix_bytes(n + 4, n + 1)
+            got = whole.copy()
+            host.cycle_via_class(got[4:], key)
+            want = whole.copy()
+            oracle.cycle(want[4:], key)
+            assert np.array_equal(got, want), (hex(key), n)
+
+
+@pytest.mark.parametrize("ps4", [True, False])
+def test_save_load_roundtrip_and_framing(host, oracle, tmp_path, ps4):
+    host.select_platform(ps4)
+    plat = "ps4" if ps4 else "ps3"
+    names, sizes, data = synth(700, 3)
+    a = host.Ark()
+    a.construct_from_table(names, sizes, 3, f"main_{plat}")
+    a.build_from_memory(data)
+    out = str(tmp_path) + "/"
+    a.save(out, f"main_{plat}.hdr")
+    # framing on disk: plaintext magic, then the oracle's ciphertext of the plain body
+    disk = np.fromfile(out + f"main_{plat}.hdr", dtype=np.uint8)
+    plain = a.serialise_header(encrypt=False)
+    want = plain.copy()
+    assert oracle.hdr_encrypt(want, ps4) == 0
+    assert np.array_equal(disk, want)
+    assert np.array_equal(a.serialise_header(encrypt=True), want)
+    # parts are raw slices (reference behaviour)
+    off = 0
+    for path, size in zip(a.ark_paths(), a.ark_sizes()):
+        assert np.array_equal(np.fromfile(out + path, dtype=np.uint8), data[off:off + size])
+        off += size
+    # Load: magic picks the key whatever the platform switch says (CArk.cpp:336)
+    host.select_platform(not ps4)
+    b = host.Ark().load(out + f"main_{plat}.hdr")
+    host.select_platform(ps4)
+    assert b.ark_sizes() == a.ark_sizes() and b.ark_paths() == a.ark_paths()
+    p = AH.parse(plain.tobytes())
+    assert [(f["name"], f["size"], f["offset"], f["flags1"], f["flags2"]) for f in b.files()] == \
+        [(f["name"], f["size"], f["offset"], f["flags1"], f["flags2"]) for f in p["files"]]
+    # Decode command writes <hdr>.dec = magic + plaintext (Modulate.cpp:452-502)
+    host.decode(out)
+    assert np.array_equal(np.fromfile(out + f"main_{plat}.hdr.dec", dtype=np.uint8), plain)
+    # AlreadyLoaded (CArk.cpp:303-306)
+    with pytest.raises(host.HostError) as e:
+        b.load(out + f"main_{plat}.hdr")
+    assert e.value.code == 5
+    a.close(), b.close()
+
+
+def test_config5_roundtrip_unpack_repack(host, oracle, tmp_path):
+    """decrypt -> unpack -> repack -> encrypt; output bytes identical to the first pack."""
+    host.select_platform(True)
+    names, sizes, data = synth(400, 9)
+    first = str(tmp_path / "first") + "/"
+    os.makedirs(first)
+    a = host.Ark()
+    a.construct_from_table(names, sizes, 4, "main_ps4")
+    a.build_from_memory(data)
+    a.save(first, "main_ps4.hdr")
+    # unpack with the CLI (Modulate.cpp:291-317)
+    unpacked = str(tmp_path / "unpacked")
+    r = subprocess.run([EXE, "-unpack", first, unpacked], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    offs = np.cumsum([0] + sizes)
+    for nm, s, o in zip(names, sizes, offs):
+        assert np.array_equal(np.fromfile(os.path.join(unpacked, nm), dtype=np.uint8), data[o:o + s]), nm
+    # repack from the directory against the first header as reference (Modulate.cpp:380-450)
+    second = str(tmp_path / "second")
+    os.makedirs(second)
+    r = subprocess.run([EXE, "-pack", first, unpacked, second], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    b = host.Ark().load(second + "/main_ps4.hdr")
+    assert sorted(f["name"] for f in b.files()) == sorted(names)
+    # extract again and compare every file (directory order differs from table order, bytes must not)
+    again = str(tmp_path / "again") + "/"
+    b.extract(again)
+    for nm, s, o in zip(names, sizes, offs):
+        assert np.array_equal(np.fromfile(os.path.join(again, nm), dtype=np.uint8), data[o:o + s]), nm
+    # a third pack from `again` reproduces the second byte for byte (fixed point of the round trip)
+    third = str(tmp_path / "third")
+    os.makedirs(third)
+    r = subprocess.run([EXE, "-pack", second, again, third], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for fn in ["main_ps4.hdr"] + b.ark_paths():
+        assert np.array_equal(np.fromfile(os.path.join(second, fn), dtype=np.uint8),
+                              np.fromfile(os.path.join(third, fn), dtype=np.uint8)), fn
+    a.close(), b.close()
+
+
+def test_config4_pack_with_part_cipher(host, oracle, tmp_path):
+    """Config 4 at test scale: synthetic table -> multi-part .ark + encrypted header, parts cycled
+    on the GPU (north_star); every part == oracle Cycle of its raw slice from stream offset 0."""
+    host.select_platform(True)
+    names, sizes, data = synth(5000, 4, max_size=4000)
+    a = host.Ark()
+    a.construct_from_table(names, sizes, 5, "main_ps4")
+    a.build_from_memory(data)
+    a.enable_part_cipher(True, 1)
+    out = str(tmp_path) + "/"
+    a.save(out, "main_ps4.hdr")
+    assert np.array_equal(a.data(), data)  # SaveArk restores the in-memory slices
+    off = 0
+    for path, size in zip(a.ark_paths(), a.ark_sizes()):
+        want = oracle.cycle(data[off:off + size].copy(), oracle.KEY_PS4)
+        assert np.array_equal(np.fromfile(out + path, dtype=np.uint8), want), path
+        off += size
+    # reading them back through LoadArkData with the part cipher on gives the raw bytes again
+    b = host.Ark().load(out + "main_ps4.hdr")
+    b.enable_part_cipher(True, 1)
+    b.load_data()
+    assert np.array_equal(b.data(), data)
+    # and the CLI path: -cryptparts -unpack
+    r = subprocess.run([EXE, "-cryptparts", "-gpus", "1", "-unpack", out, str(tmp_path / "u")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    offs = np.cumsum([0] + sizes)
+    for k in (0, 1, 77, 4999):
+        assert np.array_equal(np.fromfile(tmp_path / "u" / names[k], dtype=np.uint8), data[offs[k]:offs[k] + sizes[k]])
+    a.close(), b.close()
+
+
+def test_load_rejects_corrupt_headers(host, oracle, tmp_path):
+    host.select_platform(True)
+    names, sizes, data = synth(50, 2)
+    a = host.Ark()
+    a.construct_from_table(names, sizes, 2, "main_ps4")
+    a.build_from_memory(data)
+    img = a.serialise_header(encrypt=True)
+    for cut in (5, 31, 40, len(img) // 2, len(img) - 1):  # truncated images must fail cleanly, not crash
+        with pytest.raises(host.HostError):
+            host.Ark().parse_header(img[:cut].copy())
+    bad = img.copy()
+    bad[0] ^= 1
+    with pytest.raises(host.HostError) as e:
+        host.Ark().parse_header(bad)
+    assert e.value.code == 3
+    host.Ark().parse_header(img.copy())
+    a.close()
