@@ -130,6 +130,8 @@ class Ark:
         _check(lib().modhost_ark_construct_from_directory(self.h, os.fsencode(input_dir), reference.h))
 
     def construct_from_table(self, names, sizes, n_arks, prefix="main"):
+        if len(names) != len(sizes):
+            raise HostError(11, "names and sizes differ in length")
         blob = b"".join(n.encode("latin-1") + b"\0" for n in names)
         arr = (_u32 * len(sizes))(*sizes)
         _check(lib().modhost_ark_construct_from_table(self.h, blob, arr, len(names), n_arks, prefix.encode()))
