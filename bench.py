@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--key", type=lambda s: int(s, 0), default=0x90CFC0AB)
     ap.add_argument("--cpu-sample-bytes", type=int, default=1 << 30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier/MAX (nccl = RCCL); "
+                    "gloo is for rehearsing N>1 on a box with fewer GPUs")
+    ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: every rank uses this HIP device")
     a = ap.parse_args()
 
     import modulate_amd as M
@@ -82,12 +85,15 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        red_dev = torch.device("cuda", local_rank)
+        if a.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            red_dev = torch.device("cuda", local_rank)
+        else:
+            dist.init_process_group(a.backend)
     if M.device_count() < 1:
         raise SystemExit("no HIP device: bench.py measures the HIP path only")
-    dev = local_rank
+    dev = local_rank if a.force_device is None else a.force_device
 
     n = a.part_bytes
     # synthetic part: uniform random bytes (values do not affect timing; they make the checks real)
