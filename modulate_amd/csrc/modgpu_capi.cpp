@@ -129,42 +129,81 @@ int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_of
 }
 
 // ---- per-device staging context for host-buffer calls ----------------------------------
+//
+// A caller-owned pageable buffer goes  memcpy -> pinned -> H2D -> kernel -> D2H -> pinned -> memcpy.
+// Measured on the MI355X node (profiles/r01_ubench_hostpath.txt): the DMA engines move 57 GB/s each
+// way from pinned memory, one host thread copies pageable->pinned at 22 GB/s, four at 73 GB/s, and
+// registering the caller's pages in place costs as much as copying them.  So the work is spread
+// over kPipes independent pipelines, each a host thread with two (pinned, device, stream) slots
+// that double-buffers its own chunks; the copies of different pipelines overlap each other and
+// the (comparatively instant) kernels.  Small buffers use pipeline 0 inline, no threads.
 
-constexpr uint64_t kChunk = 32ull << 20; // bytes per pipeline stage
-constexpr int kSlots = 3;                // pinned+device slots in flight
+constexpr uint64_t kChunk = 16ull << 20; // bytes per slot
+constexpr int kPipes = 6;                // host threads / independent pipelines for large buffers
+constexpr int kSlotsPerPipe = 2;
+constexpr int kSlots = kPipes * kSlotsPerPipe;
 
 struct Staging {
     std::mutex mu;
-    bool ready = false;
     uint8_t *pinned[kSlots] = {};
     uint8_t *dev[kSlots] = {};
     hipStream_t stream[kSlots] = {};
-    uint64_t cap = 0;
+    uint64_t cap[kSlots] = {};
 };
 
 constexpr int kMaxDevices = 64;
 Staging g_staging[kMaxDevices];
 
-int staging_reserve(Staging &s, uint64_t need)
+// Slots [0, n_slots) get at least `need` bytes each (grown on demand, never shrunk).
+int staging_reserve(Staging &s, int n_slots, uint64_t need)
 {
     need = std::min<uint64_t>(std::max<uint64_t>(need, 1ull << 20), kChunk);
-    if (s.ready && s.cap >= need) return MODGPU_OK;
-    for (int i = 0; i < kSlots; ++i) {
+    for (int i = 0; i < n_slots; ++i) {
+        if (s.cap[i] >= need) continue;
         if (s.pinned[i]) HIP_TRY(hipHostFree(s.pinned[i]));
         if (s.dev[i]) HIP_TRY(hipFree(s.dev[i]));
         s.pinned[i] = nullptr;
         s.dev[i] = nullptr;
+        s.cap[i] = 0;
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.pinned[i]), need, hipHostMallocDefault));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev[i]), need));
         if (!s.stream[i]) HIP_TRY(hipStreamCreateWithFlags(&s.stream[i], hipStreamNonBlocking));
+        s.cap[i] = need;
     }
-    s.cap = need;
-    s.ready = true;
     return MODGPU_OK;
 }
 
-// H2D -> kernel -> D2H, chunked over kSlots streams so copies in both directions overlap the
-// kernel and the host-side memcpy into / out of pinned memory.
+// One pipeline: chunks first, first+stride, ... of the buffer through slots [slot0, slot0+2).
+int run_pipe(Staging &s, int slot0, uint8_t *host, uint64_t n, uint64_t chunk, uint64_t first, uint64_t stride,
+             int32_t key, uint64_t stream_off)
+{
+    const uint64_t n_chunks = (n + chunk - 1) / chunk;
+    auto span = [&](uint64_t c, uint64_t *off, uint64_t *len) {
+        *off = c * chunk;
+        *len = std::min<uint64_t>(chunk, n - *off);
+    };
+    uint64_t mine = first < n_chunks ? (n_chunks - first + stride - 1) / stride : 0;
+    for (uint64_t i = 0; i < mine + kSlotsPerPipe; ++i) {
+        int slot = slot0 + (int)(i % kSlotsPerPipe);
+        if (i >= kSlotsPerPipe) { // drain the chunk that used this slot two trips ago
+            uint64_t off, len;
+            span(first + (i - kSlotsPerPipe) * stride, &off, &len);
+            HIP_TRY(hipStreamSynchronize(s.stream[slot]));
+            std::memcpy(host + off, s.pinned[slot], len);
+        }
+        if (i < mine) {
+            uint64_t off, len;
+            span(first + i * stride, &off, &len);
+            std::memcpy(s.pinned[slot], host + off, len);
+            HIP_TRY(hipMemcpyAsync(s.dev[slot], s.pinned[slot], len, hipMemcpyHostToDevice, s.stream[slot]));
+            int rc = cycle_device_impl(s.dev[slot], len, key, stream_off + off, s.stream[slot]);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(s.pinned[slot], s.dev[slot], len, hipMemcpyDeviceToHost, s.stream[slot]));
+        }
+    }
+    return MODGPU_OK;
+}
+
 int cycle_host_impl(uint8_t *host, uint64_t n, int32_t key, uint64_t stream_off, int device)
 {
     if (n == 0) return MODGPU_OK;
@@ -176,33 +215,34 @@ int cycle_host_impl(uint8_t *host, uint64_t n, int32_t key, uint64_t stream_off,
     if (dev >= kMaxDevices) return fail(MODGPU_ERR_INVALID, "device index beyond staging table");
     Staging &s = g_staging[dev];
     std::lock_guard<std::mutex> lock(s.mu);
-    rc = staging_reserve(s, n);
-    if (rc) return rc;
 
-    const uint64_t chunk = s.cap;
+    const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n, 1ull << 20), kChunk);
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
-    auto span = [&](uint64_t c, uint64_t *off, uint64_t *len) {
-        *off = c * chunk;
-        *len = std::min<uint64_t>(chunk, n - *off);
+    const int pipes = (int)std::min<uint64_t>(kPipes, (n_chunks + 1) / 2); // a pipeline is worth >= 2 chunks
+    rc = staging_reserve(s, pipes * kSlotsPerPipe, chunk);
+    if (rc) return rc;
+    if (pipes <= 1) return run_pipe(s, 0, host, n, chunk, 0, 1, key, stream_off);
+
+    std::vector<int> rcs(pipes, MODGPU_OK);
+    std::vector<std::string> errs(pipes);
+    std::vector<std::thread> workers;
+    auto body = [&](int p) {
+        if (hipSetDevice(dev) != hipSuccess) { // HIP's current device is per thread
+            rcs[p] = MODGPU_ERR_HIP;
+            errs[p] = "hipSetDevice in staging worker";
+            return;
+        }
+        rcs[p] = run_pipe(s, p * kSlotsPerPipe, host, n, chunk, (uint64_t)p, (uint64_t)pipes, key, stream_off);
+        if (rcs[p]) errs[p] = t_err;
     };
-    for (uint64_t c = 0; c < n_chunks + kSlots; ++c) {
-        int slot = (int)(c % kSlots);
-        if (c >= kSlots) { // drain the chunk that used this slot kSlots trips ago
-            uint64_t off, len;
-            span(c - kSlots, &off, &len);
-            HIP_TRY(hipStreamSynchronize(s.stream[slot]));
-            std::memcpy(host + off, s.pinned[slot], len);
+    for (int p = 1; p < pipes; ++p) workers.emplace_back(body, p);
+    body(0);
+    for (auto &w : workers) w.join();
+    for (int p = 0; p < pipes; ++p)
+        if (rcs[p]) {
+            t_err = errs[p];
+            return rcs[p];
         }
-        if (c < n_chunks) {
-            uint64_t off, len;
-            span(c, &off, &len);
-            std::memcpy(s.pinned[slot], host + off, len);
-            HIP_TRY(hipMemcpyAsync(s.dev[slot], s.pinned[slot], len, hipMemcpyHostToDevice, s.stream[slot]));
-            rc = cycle_device_impl(s.dev[slot], len, key, stream_off + off, s.stream[slot]);
-            if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(s.pinned[slot], s.dev[slot], len, hipMemcpyDeviceToHost, s.stream[slot]));
-        }
-    }
     return MODGPU_OK;
 }
 

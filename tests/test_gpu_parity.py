@@ -109,8 +109,8 @@ def test_split_stream_equals_one_call(gpu, oracle):
 
 
 def test_host_path_chunk_boundaries(gpu, oracle):
-    """Host API across its internal staging chunks (32 MiB) and slot ring."""
-    for n in ((32 << 20) - 1, (32 << 20) + 1, (100 << 20) + 3):
+    """Host API across its internal staging chunks (16 MiB), slot rings and 1..6 worker pipelines."""
+    for n in ((16 << 20) - 1, (16 << 20) + 1, (32 << 20) + 1, (100 << 20) + 3, (208 << 20) + 5):
         pt = oracle.splitmix_bytes(n, n)
         ct = gpu.cycle_host(pt.copy(), 0xC64EED30)
         assert np.array_equal(ct, oracle.cycle(pt.copy(), 0xC64EED30)), n
