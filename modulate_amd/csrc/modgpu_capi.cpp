@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -134,14 +135,25 @@ int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_of
 // Measured on the MI355X node (profiles/r01_ubench_hostpath.txt): the DMA engines move 57 GB/s each
 // way from pinned memory, one host thread copies pageable->pinned at 22 GB/s, four at 73 GB/s, and
 // registering the caller's pages in place costs as much as copying them.  So the work is spread
-// over kPipes independent pipelines, each a host thread with two (pinned, device, stream) slots
+// over kPipes (4) independent pipelines, each a host thread with two (pinned, device, stream) slots
 // that double-buffers its own chunks; the copies of different pipelines overlap each other and
 // the (comparatively instant) kernels.  Small buffers use pipeline 0 inline, no threads.
 
-constexpr uint64_t kChunk = 16ull << 20; // bytes per slot
-constexpr int kPipes = 6;                // host threads / independent pipelines for large buffers
+constexpr int kMaxPipes = 16;
 constexpr int kSlotsPerPipe = 2;
-constexpr int kSlots = kPipes * kSlotsPerPipe;
+constexpr int kSlots = kMaxPipes * kSlotsPerPipe;
+
+// Tunables (read once): MODGPU_HOST_PIPES = host threads / independent pipelines for large buffers,
+// MODGPU_HOST_CHUNK_MB = bytes per slot in MiB.
+int env_int(const char *name, int dflt, int lo, int hi)
+{
+    const char *v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    int x = std::atoi(v);
+    return x < lo ? lo : (x > hi ? hi : x);
+}
+const int kPipes = env_int("MODGPU_HOST_PIPES", 4, 1, kMaxPipes);
+const uint64_t kChunk = (uint64_t)env_int("MODGPU_HOST_CHUNK_MB", 16, 1, 256) << 20;
 
 struct Staging {
     std::mutex mu;
@@ -216,9 +228,12 @@ int cycle_host_impl(uint8_t *host, uint64_t n, int32_t key, uint64_t stream_off,
     Staging &s = g_staging[dev];
     std::lock_guard<std::mutex> lock(s.mu);
 
-    const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n, 1ull << 20), kChunk);
+    // slot size: the whole buffer if it is small, else ~n/16 between 4 MiB and the cap (measured:
+    // 4 MiB slots are best at 64 MiB, 16 MiB slots from 1 GiB up; profiles/r01_sweep_hostpath.txt)
+    uint64_t chunk = n <= (4ull << 20) ? std::max<uint64_t>(n, 1ull << 20)
+                                       : std::min<uint64_t>(kChunk, std::max<uint64_t>(4ull << 20, ((n >> 4) + 0xFFFFF) & ~0xFFFFFull));
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
-    const int pipes = (int)std::min<uint64_t>(kPipes, (n_chunks + 1) / 2); // a pipeline is worth >= 2 chunks
+    const int pipes = (int)std::min<uint64_t>((uint64_t)kPipes, (n_chunks + 1) / 2); // a pipeline is worth >= 2 chunks
     rc = staging_reserve(s, pipes * kSlotsPerPipe, chunk);
     if (rc) return rc;
     if (pipes <= 1) return run_pipe(s, 0, host, n, chunk, 0, 1, key, stream_off);
