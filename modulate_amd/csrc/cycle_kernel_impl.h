@@ -93,7 +93,8 @@ template <int ALG> __device__ __forceinline__ u32x4 cycle_word(u32x4 d, uint32_t
 __device__ __forceinline__ uint8_t cycle_byte(uint8_t d, uint32_t s) { return (uint8_t)~(d ^ (uint8_t)s); }
 
 enum : int { MODE_FULL = 0, MODE_COPY = 1, MODE_COMPUTE = 2 };
-constexpr int AUX_NT = 2; // buffer cache-policy bit: non-temporal (streaming)
+constexpr int AUX_NT = 2;   // buffer cache-policy bit: non-temporal (streaming) -- best for the loads (7.0 vs 6.4 TB/s read-only)
+constexpr int AUX_SC1 = 16; // system-coherent / write-through -- best for the stores (6.3 vs 5.9 TB/s write-only)
 
 } // namespace
 
@@ -106,8 +107,9 @@ constexpr int AUX_NT = 2; // buffer cache-policy bit: non-temporal (streaming)
 // Addressing is buffer_load/store_dwordx4 through a per-trip descriptor built from scalars:
 // no per-lane 64-bit pointer arithmetic in the loop, and the hardware range check (num_records =
 // bytes left in the body, capped at the chunk) drops the lanes past the end of a ragged last
-// chunk -- there is no tail branch.
-template <int U, int BLOCK, int ALG, bool PIPE, int MODE>
+// chunk -- there is no tail branch.  Loads are `nt`, stores `sc1` (SAUX): measured best per direction
+// (profiles/r01_ubench_copy_policies.txt).
+template <int U, int BLOCK, int ALG, bool PIPE, int MODE, int SAUX = AUX_SC1>
 __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
 {
     static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
@@ -174,8 +176,8 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
         for (int u = 0; u < U; ++u) {
             if constexpr (MODE == MODE_COMPUTE) {
                 if ((d[u].x ^ d[u].y ^ d[u].z ^ d[u].w) == 0x9E3779B9u && s[u] == 1u)
-                    __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, AUX_NT);
-            } else __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, AUX_NT);
+                    __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
+            } else __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
         }
     };
 

@@ -23,9 +23,9 @@ struct Variant {
     std::vector<float> ms;
 };
 
-template <int U, int BLOCK, int ALG, bool PIPE, int MODE> void launch(const CycleArgs &a, uint32_t grid, hipStream_t st)
+template <int U, int BLOCK, int ALG, bool PIPE, int MODE, int SAUX = 16> void launch(const CycleArgs &a, uint32_t grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((modgpu_cycle_kernel<U, BLOCK, ALG, PIPE, MODE>), dim3(grid), dim3(BLOCK), 0, st, a);
+    hipLaunchKernelGGL((modgpu_cycle_kernel<U, BLOCK, ALG, PIPE, MODE, SAUX>), dim3(grid), dim3(BLOCK), 0, st, a);
 }
 
 int main(int argc, char **argv)
@@ -48,27 +48,23 @@ int main(int argc, char **argv)
         snprintf(b_, sizeof b_, "%-7s U=%d B=%4d alg=%d pipe=%d grid=%5u", MODE == MODE_FULL ? "full" : MODE == MODE_COPY ? "copy" : "compute", U, B, ALG, (int)PIPE, (unsigned)(g)); \
         vs.push_back({b_, launch<U, B, ALG, PIPE, MODE>, (uint64_t)U * B * 16, (g), {}});                     \
     } while (0)
+#define ADDS(U, B, ALG, PIPE, MODE, SAUX, g)                                                                  \
+    do {                                                                                                     \
+        char b_[128];                                                                                        \
+        snprintf(b_, sizeof b_, "%-7s U=%d B=%4d alg=%d pipe=%d st=%2d grid=%5u", MODE == MODE_FULL ? "full" : MODE == MODE_COPY ? "copy" : "compute", U, B, ALG, (int)PIPE, SAUX, (unsigned)(g)); \
+        vs.push_back({b_, launch<U, B, ALG, PIPE, MODE, SAUX>, (uint64_t)U * B * 16, (g), {}});               \
+    } while (0)
     for (uint32_t g : {256u, 512u, 1024u}) {
-        ADD(4, 1024, 0, false, MODE_FULL, g);
-        ADD(4, 1024, 1, false, MODE_FULL, g);
-        ADD(4, 1024, 0, true, MODE_FULL, g);
-        ADD(4, 1024, 1, true, MODE_FULL, g);
-        ADD(2, 1024, 1, true, MODE_FULL, g);
-        ADD(8, 1024, 1, false, MODE_FULL, g);
-        ADD(8, 512, 1, true, MODE_FULL, g);
-        ADD(4, 512, 1, true, MODE_FULL, g);
-        ADD(4, 256, 1, true, MODE_FULL, g);
-        ADD(4, 256, 1, false, MODE_FULL, g);
-        ADD(4, 1024, 1, false, MODE_COPY, g);
-        ADD(4, 1024, 1, true, MODE_COPY, g);
-        ADD(4, 1024, 0, false, MODE_COMPUTE, g);
-        ADD(4, 1024, 1, false, MODE_COMPUTE, g);
+        ADDS(4, 1024, 1, true, MODE_FULL, 2, g);
+        ADDS(4, 1024, 1, true, MODE_FULL, 16, g);
+        ADDS(4, 1024, 0, true, MODE_FULL, 16, g);
+        ADDS(4, 1024, 0, false, MODE_FULL, 16, g);
+        ADDS(4, 1024, 1, false, MODE_FULL, 16, g);
+        ADDS(8, 1024, 1, false, MODE_FULL, 16, g);
+        ADDS(4, 1024, 1, true, MODE_COPY, 2, g);
+        ADDS(4, 1024, 1, true, MODE_COPY, 16, g);
+        ADDS(4, 1024, 1, false, MODE_COPY, 16, g);
     }
-    ADD(4, 256, 1, false, MODE_FULL, 2048u);
-    ADD(4, 256, 0, false, MODE_FULL, 2048u);
-    ADD(4, 256, 1, true, MODE_FULL, 2048u);
-    ADD(1, 256, 1, false, MODE_FULL, 16384u);
-
     CycleArgs a{};
     a.head_ptr = buf; a.head_n = 0; a.body = buf; a.body_words = n / 16; a.tail_ptr = buf + n; a.tail_n = 0;
     a.base_head = a.base_body = a.base_tail = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);

@@ -85,12 +85,114 @@ __global__ void write_k(u32x4 *dst, uint64_t n_words)
     for (; i < n_words; i += st) __builtin_nontemporal_store(v, dst + i);
 }
 
+
+// ---- layout experiments on the 1024-thread / 64 KiB shape ---------------------------------
+// MAP 0: chunk = block, grid-stride.  MAP 1: XCD-aware -- blocks with equal (blockIdx % 8) share an
+// XCD (observed round-robin dispatch); give each XCD one contiguous eighth of the buffer.
+// WAVEC: wave-contiguous -- a wave's U loads are adjacent (U KiB per wave) instead of BLOCK*16 apart.
+template <int U, int BLOCK, int MAP, bool WAVEC, int RW>
+__global__ __launch_bounds__(BLOCK) void shape_k(uint8_t *src, uint8_t *dst, uint64_t n_bytes, uint32_t *sink)
+{
+    constexpr uint64_t TRIP = (uint64_t)U * BLOCK * 16;
+    const uint64_t trips = n_bytes / TRIP;
+    uint64_t t0, t1, step;
+    if (MAP == 0) { t0 = blockIdx.x; t1 = trips; step = gridDim.x; }
+    else { uint64_t per = trips / 8; uint32_t x = blockIdx.x & 7, j = blockIdx.x >> 3; t0 = x * per + j; t1 = (x + 1) * per; step = gridDim.x >> 3; }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32x4 acc = 0;
+    for (uint64_t t = t0; t < t1; t += step) {
+        auto rs = __builtin_amdgcn_make_buffer_rsrc(src + t * TRIP, 0, (int)TRIP, 0x00020000);
+        auto rd = __builtin_amdgcn_make_buffer_rsrc(dst + t * TRIP, 0, (int)TRIP, 0x00020000);
+        u32x4 d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t off = WAVEC ? (wave * U + u) * 1024 + lane * 16 : threadIdx.x * 16 + u * BLOCK * 16;
+            if (RW & 1) d[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 2);
+            else d[u] = u32x4{(uint32_t)t, off, 1u, 2u};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t off = WAVEC ? (wave * U + u) * 1024 + lane * 16 : threadIdx.x * 16 + u * BLOCK * 16;
+            if (RW & 2) __builtin_amdgcn_raw_buffer_store_b128(~d[u], rd, off, 0, 2);
+            else acc ^= d[u];
+        }
+    }
+    if (!(RW & 2) && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345) sink[0] = 1;
+}
+
+
+// write-only / read-only policy sweep on the 1024 x U shape (AUX: 1 = sc0, 2 = nt, 16 = sc1)
+template <int U, int BLOCK, int AUX, bool WRITE>
+__global__ __launch_bounds__(BLOCK) void pol_k(uint8_t *buf, uint64_t n_bytes, uint32_t *sink)
+{
+    constexpr uint64_t TRIP = (uint64_t)U * BLOCK * 16;
+    const uint64_t trips = n_bytes / TRIP;
+    u32x4 acc = 0;
+    for (uint64_t t = blockIdx.x; t < trips; t += gridDim.x) {
+        auto r = __builtin_amdgcn_make_buffer_rsrc(buf + t * TRIP, 0, (int)TRIP, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t off = threadIdx.x * 16 + u * BLOCK * 16;
+            if (WRITE) __builtin_amdgcn_raw_buffer_store_b128(u32x4{(uint32_t)t, off, 1u, 2u}, r, off, 0, AUX);
+            else acc ^= __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX);
+        }
+    }
+    if (!WRITE && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345) sink[0] = 1;
+}
+
+
+// mixed in-place read-modify-write on the 1024 x U shape with independent load / store policies
+template <int U, int BLOCK, int LA, int SA, bool PIPE>
+__global__ __launch_bounds__(BLOCK) void mix_k(uint8_t *buf, uint64_t n_bytes)
+{
+    constexpr uint64_t TRIP = (uint64_t)U * BLOCK * 16;
+    const uint64_t trips = n_bytes / TRIP;
+    const uint32_t voff = threadIdx.x * 16;
+    uint64_t t = blockIdx.x;
+    if (t >= trips) return;
+    if (!PIPE) {
+        for (; t < trips; t += gridDim.x) {
+            auto r = __builtin_amdgcn_make_buffer_rsrc(buf + t * TRIP, 0, (int)TRIP, 0x00020000);
+            u32x4 d[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * BLOCK * 16, 0, LA);
+#pragma unroll
+            for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(~d[u], r, voff + u * BLOCK * 16, 0, SA);
+        }
+    } else {
+        u32x4 cur[U], nxt[U];
+        {
+            auto r = __builtin_amdgcn_make_buffer_rsrc(buf + t * TRIP, 0, (int)TRIP, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * BLOCK * 16, 0, LA);
+        }
+        for (; t < trips; t += gridDim.x) {
+            uint64_t tn = t + gridDim.x;
+            auto rn = __builtin_amdgcn_make_buffer_rsrc(buf + tn * TRIP, 0, tn < trips ? (int)TRIP : 0, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = __builtin_amdgcn_raw_buffer_load_b128(rn, voff + u * BLOCK * 16, 0, LA);
+            auto r = __builtin_amdgcn_make_buffer_rsrc(buf + t * TRIP, 0, (int)TRIP, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(~cur[u], r, voff + u * BLOCK * 16, 0, SA);
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        }
+    }
+}
+
 struct V { std::string name; void (*fn)(uint8_t *, uint8_t *, uint64_t, uint32_t, hipStream_t); uint32_t grid; bool inplace; double bytes_factor; std::vector<float> ms; };
 
 template <int U, int BLOCK, int LA, int SA, bool CONTIG> void L(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st)
 { hipLaunchKernelGGL((copy_k<U, BLOCK, LA, SA, CONTIG>), dim3(g), dim3(BLOCK), 0, st, s, d, n); }
 template <int U, int BLOCK, int LA, int SA> void LP(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st)
 { hipLaunchKernelGGL((copy_pipe_k<U, BLOCK, LA, SA>), dim3(g), dim3(BLOCK), 0, st, s, d, n); }
+static uint32_t *g_sink;
+template <int U, int BLOCK, int MAP, bool WAVEC, int RW> void LS(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st)
+{ hipLaunchKernelGGL((shape_k<U, BLOCK, MAP, WAVEC, RW>), dim3(g), dim3(BLOCK), 0, st, s, d, n, g_sink); }
+template <int U, int BLOCK, int AUX, bool WRITE> void LPOL(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st)
+{ hipLaunchKernelGGL((pol_k<U, BLOCK, AUX, WRITE>), dim3(g), dim3(BLOCK), 0, st, s, n, g_sink); }
+template <int U, int BLOCK, int LA, int SA, bool PIPE> void LMIX(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st)
+{ hipLaunchKernelGGL((mix_k<U, BLOCK, LA, SA, PIPE>), dim3(g), dim3(BLOCK), 0, st, s, n); }
 void LR(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st) { hipLaunchKernelGGL(read_k, dim3(g), dim3(256), 0, st, (const u32x4 *)s, n / 16, (uint32_t *)d); }
 void LW(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st) { hipLaunchKernelGGL(write_k, dim3(g), dim3(256), 0, st, (u32x4 *)s, n / 16); }
 void LM(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st) { (void)hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st); }
@@ -104,35 +206,27 @@ int main(int argc, char **argv)
     CHECK(hipMemset(a, 0x5A, n)); CHECK(hipMemset(b, 0x11, n));
     hipStream_t st; CHECK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    CHECK(hipMalloc(&g_sink, 64));
     std::vector<V> vs;
     auto add = [&](const char *nm, decltype(V::fn) fn, uint32_t g, bool inpl, double f = 2.0) {
         char buf[128]; snprintf(buf, sizeof buf, "%-34s grid=%5u %s", nm, g, inpl ? "in-place " : "out-of-pl");
         vs.push_back({buf, fn, g, inpl, f, {}});
     };
-    add("read-only nt U4", LR, 2048, true, 1.0);
-    add("write-only nt", LW, 2048, true, 1.0);
-    add("hipMemcpyDtoD", LM, 0, false);
-    for (bool inpl : {true, false}) {
-        for (uint32_t g : {256u, 512u, 1024u, 2048u}) {
-            add("U4 B256 ld=nt st=nt stride", L<4, 256, 2, 2, false>, g, inpl);
-            add("U8 B256 ld=nt st=nt stride", L<8, 256, 2, 2, false>, g, inpl);
-            add("U4 B256 ld=nt st=nt contig", L<4, 256, 2, 2, true>, g, inpl);
-            add("U4 B256 ld=0  st=0  stride", L<4, 256, 0, 0, false>, g, inpl);
-            add("U4 B256 ld=nt st=0  stride", L<4, 256, 2, 0, false>, g, inpl);
-            add("U4 B256 ld=0  st=nt stride", L<4, 256, 0, 2, false>, g, inpl);
-            add("U4 B256 ld=sc1 st=sc1 stride", L<4, 256, 16, 16, false>, g, inpl);
-            add("U4 B256 ld=sc0sc1 st=sc0sc1", L<4, 256, 17, 17, false>, g, inpl);
-            add("U4 B256 ld=nt+sc1 st=nt+sc1", L<4, 256, 18, 18, false>, g, inpl);
-            add("U4 B256 ld=all st=all", L<4, 256, 19, 19, false>, g, inpl);
-            add("U4 B256 pipe ld=nt st=nt", LP<4, 256, 2, 2>, g, inpl);
-            add("U8 B256 pipe ld=nt st=nt", LP<8, 256, 2, 2>, g, inpl);
-        }
-        for (uint32_t g : {256u, 512u, 1024u}) {
-            add("U4 B512 ld=nt st=nt stride", L<4, 512, 2, 2, false>, g, inpl);
-            add("U2 B1024 ld=nt st=nt stride", L<2, 1024, 2, 2, false>, g, inpl);
-            add("U4 B1024 ld=nt st=nt stride", L<4, 1024, 2, 2, false>, g, inpl);
-            add("U4 B512 pipe ld=nt st=nt", LP<4, 512, 2, 2>, g, inpl);
-        }
+    CHECK(hipMalloc(&g_sink, 64));
+    for (uint32_t g : {256u, 512u, 768u, 1024u}) {
+        add("mix U4 ld=nt st=nt", LMIX<4, 1024, 2, 2, false>, g, true);
+        add("mix U4 ld=nt st=sc1", LMIX<4, 1024, 2, 16, false>, g, true);
+        add("mix U4 ld=nt st=sc0sc1", LMIX<4, 1024, 2, 17, false>, g, true);
+        add("mix U4 ld=nt st=0", LMIX<4, 1024, 2, 0, false>, g, true);
+        add("mix U4 ld=nt st=nt+sc1", LMIX<4, 1024, 2, 18, false>, g, true);
+        add("mix U4 ld=nt+sc1 st=sc1", LMIX<4, 1024, 18, 16, false>, g, true);
+        add("mix U4 ld=0 st=sc1", LMIX<4, 1024, 0, 16, false>, g, true);
+        add("mix U4 pipe ld=nt st=nt", LMIX<4, 1024, 2, 2, true>, g, true);
+        add("mix U4 pipe ld=nt st=sc1", LMIX<4, 1024, 2, 16, true>, g, true);
+        add("mix U4 pipe ld=nt st=0", LMIX<4, 1024, 2, 0, true>, g, true);
+        add("mix U8 ld=nt st=sc1", LMIX<8, 1024, 2, 16, false>, g, true);
+        add("mix U2 pipe ld=nt st=sc1", LMIX<2, 1024, 2, 16, true>, g, true);
+        add("mix U8 B512 ld=nt st=sc1", LMIX<8, 512, 2, 16, false>, g, true);
     }
     for (int r = 0; r < rounds + 1; ++r)
         for (auto &v : vs) {
