@@ -7,7 +7,7 @@
 set -e
 TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.log 2>&1
