@@ -60,7 +60,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, "libmodulate_host.so")
+        # MODULATE_HOST_LIB: alternative build of the same library (the ASan/UBSan one, tests/test_sanitizers.py)
+        path = os.environ.get("MODULATE_HOST_LIB") or os.path.join(_HERE, "libmodulate_host.so")
         if not os.path.exists(path):
             raise HostError(-1, f"{path} not built: make -C modulate_amd/csrc")
         L = ctypes.CDLL(path)

@@ -164,6 +164,25 @@ def test_2g_boundary_device(gpu, oracle):
     dbuf.free()
 
 
+def test_beyond_4gib_offsets_device(gpu, oracle):
+    """n > 2^32 in ONE call (the reference's `unsigned int` length cannot express it),
+    misaligned base, large stream_off: exercises the 64-bit chunk offsets inside the kernel."""
+    n = (1 << 32) + 200_003
+    base, so = 5, (1 << 33) + 7
+    key = 0xC64EED30
+    dbuf = gpu.DeviceBuffer(n + 32)
+    zeros = np.zeros(1 << 28, np.uint8)
+    for o in range(0, n + 32, 1 << 28):
+        dbuf.upload(zeros[:min(1 << 28, n + 32 - o)], offset=o)
+    dbuf.cycle(key, n=n, offset=base, stream_off=so)
+    dbuf.sync()
+    for off in (0, 65531, (1 << 31) - 100, (1 << 32) - 70000, (1 << 32) - 3, (1 << 32) + 65536 - 11, n - 70001):
+        ln = min(70001, n - off)
+        assert np.array_equal(dbuf.download(ln, offset=base + off), oracle.keystream(key, ln, so + off)), off
+    assert not dbuf.download(base, 0).any() and not dbuf.download(32 - base, base + n).any()
+    dbuf.free()
+
+
 def test_config2_4gib_part_roundtrip(gpu, oracle, golden):
     """BASELINE config 2: one 2^32-byte part on one MI355X, encrypt then decrypt.
     Pass 1 is checked against the oracle on windows + the reference's own 2^32-1 byte golden
