@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "CArk.h"
+#include "CDtaFile.h"
 #include "CEncryptionCycler.h"
 #include "Commands.h"
 #include "Settings.h"
@@ -57,6 +58,27 @@ int modhost_cycle_via_class( uint8_t* buf, uint32_t n, int32_t key, int device )
 }
 
 int modhost_decode( const char* dir ) { return Guard( [ & ] { return Decode( dir ? dir : "" ); } ); }
+
+int modhost_dta_roundtrip( const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* size, char* dump, uint64_t dump_cap )
+{
+    return Guard( [ & ] {
+        CDtaFile f;
+        eError e = f.LoadFromMemory( in, (size_t)n );
+        if( e != eError_NoError ) return e;
+        std::vector< unsigned char > o;
+        f.SaveToMemory( o );
+        if( size ) *size = o.size();
+        if( out && cap ) std::memcpy( out, o.data(), (size_t)std::min< uint64_t >( cap, o.size() ) );
+        if( dump && dump_cap )
+        {
+            std::string d = f.Dump();
+            size_t k = (size_t)std::min< uint64_t >( dump_cap - 1, d.size() );
+            std::memcpy( dump, d.data(), k );
+            dump[ k ] = 0;
+        }
+        return eError_NoError;
+    } );
+}
 
 void* modhost_ark_new( void ) { return new CArk(); }
 void modhost_ark_free( void* ark ) { delete A( ark ); }

@@ -20,6 +20,9 @@ int modhost_cycle_via_class(uint8_t *buf, uint32_t n, int32_t key, int device);
 /* Decode command (Modulate.cpp:452-502): <dir>/main_<platform>.hdr -> <same>.dec */
 int modhost_decode(const char *dir);
 
+/* CDtaFile: parse `in`, re-serialise into out (min(cap,size) bytes), text dump into dump (NUL-terminated, truncated to dump_cap) */
+int modhost_dta_roundtrip(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *size, char *dump, uint64_t dump_cap);
+
 void *modhost_ark_new(void);
 void modhost_ark_free(void *ark);
 int modhost_ark_load(void *ark, const char *header_path);

@@ -19,6 +19,7 @@ HOOKS = {
     "modhost_set_flags": (None, [_int, _int, _int, _int]),
     "modhost_cycle_via_class": (_int, [_vp, _u32, _i32, _int]),
     "modhost_decode": (_int, [_cp]),
+    "modhost_dta_roundtrip": (_int, [_vp, _u64, _vp, _u64, ctypes.POINTER(_u64), _cp, _u64]),
     "modhost_ark_new": (_vp, []),
     "modhost_ark_free": (None, [_vp]),
     "modhost_ark_load": (_int, [_vp, _cp]),
@@ -96,6 +97,17 @@ def cycle_via_class(buf, key, device=-1):
 
 def decode(directory):
     _check(lib().modhost_decode(os.fsencode(directory)))
+
+
+def dta_roundtrip(blob):
+    """CDtaFile: parse a binary DTA image, return (re-serialised bytes, text dump)."""
+    blob = np.ascontiguousarray(np.frombuffer(bytes(blob), dtype=np.uint8))
+    out = np.empty(max(1, 2 * blob.size + 64), dtype=np.uint8)
+    size = _u64(0)
+    dump = ctypes.create_string_buffer(max(1 << 16, 64 * blob.size))
+    _check(lib().modhost_dta_roundtrip(_vp(blob.ctypes.data), blob.size, _vp(out.ctypes.data), out.size,
+                                       ctypes.byref(size), dump, len(dump)))
+    return out[:size.value].tobytes(), dump.value.decode("latin-1")
 
 
 class Ark:

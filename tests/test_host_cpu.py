@@ -123,3 +123,38 @@ def test_cli_usage_and_unknown_flag():
     assert r.returncode != 0 and "Unkown parameter" in r.stdout  # the reference's own spelling (Modulate.cpp:962)
     r = subprocess.run([exe, "-decode", "/nonexistent"], capture_output=True, text=True)
     assert r.returncode != 0 and "ERROR: Failed to open file" in r.stdout
+
+
+# ---- binary DTA tree (parity unpinned) -------------------------------------
+def test_dta_roundtrip_matches_restatement(host):
+    from oracle import dta_tree as DT
+    rng = np.random.default_rng(12)
+    tree = DT.synth_tree(rng, target_bytes=4000)
+    blob = DT.serialise(tree)
+    assert DT.parse(blob) == tree
+    out, dump = host.dta_roundtrip(blob)
+    assert out == blob                      # C++ writer == Python writer on the C++ parse of the Python image
+    assert dump == DT.dump(tree)            # node for node
+    # several top-level trees (the reference's Save cannot round-trip these; ours writes the separators Load expects)
+    multi = [tree[0], ("tree", 17, 9, [("int", 0, 5)]), ("tree", 16, 3, [("str", 5, "x"), ("float", 1, 0x40490FDB)])]
+    blob2 = DT.serialise(multi)
+    out2, dump2 = host.dta_roundtrip(blob2)
+    assert out2 == blob2 and dump2 == DT.dump(multi)
+
+
+def test_dta_rejects_bad_images(host):
+    from oracle import dta_tree as DT
+    tree = DT.synth_tree(np.random.default_rng(1), target_bytes=600)
+    blob = DT.serialise(tree)
+    for cut in (0, 4, 6, 9, 40, len(blob) - 1):
+        with pytest.raises(host.HostError) as e:
+            host.dta_roundtrip(blob[:cut])
+        assert e.value.code == 6  # eError_InvalidData
+    bad = bytearray(blob)
+    bad[9:13] = (77).to_bytes(4, "little")  # unknown child type (CDtaFile.cpp:503-504)
+    with pytest.raises(host.HostError):
+        host.dta_roundtrip(bytes(bad))
+    zero = bytearray(blob)
+    zero[5:7] = (0).to_bytes(2, "little")  # a tree with no children is invalid (CDtaFile.cpp:398-401)
+    with pytest.raises(host.HostError):
+        host.dta_roundtrip(bytes(zero))

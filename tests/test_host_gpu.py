@@ -173,3 +173,19 @@ def test_load_rejects_corrupt_headers(host, oracle, tmp_path):
     assert e.value.code == 3
     host.Ark().parse_header(img.copy())
     a.close()
+
+
+def test_config1_4k_dta_blob_decrypt_and_parse(host, oracle, modgpu):
+    """BASELINE config 1 made concrete: a ~4 KiB binary DTA tree, framed magic || Cycle(rest) like a
+    header (the reference itself keeps .dta files in plaintext), GPU-decrypted, parsed."""
+    from oracle import dta_tree as DT
+    tree = DT.synth_tree(np.random.default_rng(4096), target_bytes=4092)
+    body = np.frombuffer(DT.serialise(tree), dtype=np.uint8)
+    for ps4 in (True, False):
+        framed = np.concatenate([np.zeros(4, np.uint8), body])
+        modgpu.hdr_encrypt_host(framed, ps4)
+        want = np.concatenate([np.zeros(4, np.uint8), body])
+        assert oracle.hdr_encrypt(want, ps4) == 0 and np.array_equal(framed, want)
+        modgpu.hdr_decrypt_host(framed)
+        out, dump = host.dta_roundtrip(framed[4:].tobytes())
+        assert out == body.tobytes() and dump == DT.dump(tree)
