@@ -157,7 +157,7 @@ def main():
                        "bit_exact_check": "pass" if n_ok == world else "FAIL"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "modgpu_cycle_kernel<4, 1024, 1, true, 0, 16>", "ms_per_launch": round(ms_per_launch, 4),
+                         "kernel": "modgpu_cycle_kernel<8, 1024, 1, 2, 0, 16, 3>", "ms_per_launch": round(ms_per_launch, 4),
                          "algorithmic_bytes_per_launch": 2 * n},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -21,7 +21,7 @@ struct CycleArgs {
 // chunks.  grid * chunk_bytes / 4096 must stay <= 65536 (two-level tile jump table).
 enum CycleVariant : int {
     CYCLE_SMALL = 0, // 256 threads x 1 word : 4 KiB chunks, headers and other small buffers
-    CYCLE_LARGE = 1, // 1024 threads x 4 words, software-pipelined: 64 KiB chunks, streaming parts
+    CYCLE_LARGE = 1, // 1024 threads x 8 words, software-pipelined, workgroup-synchronous bursts: 128 KiB chunks
 };
 uint32_t modgpu_variant_chunk_bytes(int variant);
 

@@ -19,14 +19,14 @@
 
 uint32_t modgpu_variant_chunk_bytes(int variant)
 {
-    return variant == CYCLE_LARGE ? 4u * 1024u * lcg::WORD : 1u * 256u * lcg::WORD;
+    return variant == CYCLE_LARGE ? 8u * 1024u * lcg::WORD : 1u * 256u * lcg::WORD;
 }
 
 hipError_t modgpu_launch_cycle(const CycleArgs &a, int variant, uint32_t grid, hipStream_t stream)
 {
     if (variant == CYCLE_LARGE)
-        hipLaunchKernelGGL((modgpu_cycle_kernel<4, 1024, 1, true, MODE_FULL>), dim3(grid), dim3(1024), 0, stream, a);
+        hipLaunchKernelGGL((modgpu_cycle_kernel<8, 1024, 1, 2, MODE_FULL, AUX_SC1, 3>), dim3(grid), dim3(1024), 0, stream, a);
     else
-        hipLaunchKernelGGL((modgpu_cycle_kernel<1, 256, 1, false, MODE_FULL>), dim3(grid), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((modgpu_cycle_kernel<1, 256, 1, 0, MODE_FULL>), dim3(grid), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

@@ -101,7 +101,12 @@ constexpr int AUX_SC1 = 16; // system-coherent / write-through -- best for the s
 // U     = lane-words per thread per trip (independent 16-byte loads in flight per lane)
 // BLOCK = threads per workgroup; one workgroup trip covers U*BLOCK*16 contiguous bytes
 // ALG   = keystream instruction sequence (see ks_state_dword)
-// PIPE  = software pipeline: the next trip's loads are issued before this trip's arithmetic
+// PIPE  = 0: load, compute, store per trip.  1: software pipeline, the next trip's loads are issued
+//         before this trip's arithmetic.  2: same, with a scheduling barrier that keeps the compiler
+//         from hoisting arithmetic above those loads.  3: as 2, and each word is stored as soon as it
+//         is finished instead of all U at the end of the trip
+// SYNC  = bit 0: workgroup barrier before each trip's loads, bit 1: before its stores -- keeps the
+//         16 waves of a workgroup in step so its 64 KiB of reads and of writes reach HBM as bursts
 // MODE  = MODE_FULL in the product; the other two are timing ablations for tools/tune_cycle
 //
 // Addressing is buffer_load/store_dwordx4 through a per-trip descriptor built from scalars:
@@ -109,7 +114,7 @@ constexpr int AUX_SC1 = 16; // system-coherent / write-through -- best for the s
 // bytes left in the body, capped at the chunk) drops the lanes past the end of a ragged last
 // chunk -- there is no tail branch.  Loads are `nt`, stores `sc1` (SAUX): measured best per direction
 // (profiles/r01_ubench_copy_policies.txt).
-template <int U, int BLOCK, int ALG, bool PIPE, int MODE, int SAUX = AUX_SC1>
+template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = AUX_SC1, int SYNC = 0>
 __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
 {
     static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
@@ -164,6 +169,16 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
     };
     auto process_store = [&](u32x4(&d)[U], uint64_t o) {
         auto r = rsrc_at(o);
+        if constexpr (PIPE == 3 && MODE == MODE_FULL) { // store each word as soon as it is done
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                d[u] = cycle_word<ALG>(d[u], s[u]);
+                __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
+                s[u] = mulmod_canon(s[u], a.stride_mul);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if constexpr (MODE == MODE_COPY) d[u] = ~d[u];
@@ -171,6 +186,10 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
                 d[u] = cycle_word<ALG>(d[u], s[u]);
                 s[u] = mulmod_canon(s[u], a.stride_mul);
             }
+        }
+        if constexpr ((SYNC & 2) != 0 && PIPE != 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -181,7 +200,7 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
         }
     };
 
-    if constexpr (!PIPE) {
+    if constexpr (PIPE == 0) {
         for (; off < body_bytes; off += step) {
             u32x4 d[U];
             load(d, off);
@@ -193,11 +212,15 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
         u32x4 d0[U], d1[U];
         load(d0, off);
         while (true) {
+            if constexpr (SYNC & 1) __builtin_amdgcn_s_barrier();
             load(d1, off + step);
+            if constexpr (PIPE >= 2) __builtin_amdgcn_sched_barrier(0);
             process_store(d0, off);
             off += step;
             if (off >= body_bytes) break;
+            if constexpr (SYNC & 1) __builtin_amdgcn_s_barrier();
             load(d0, off + step);
+            if constexpr (PIPE >= 2) __builtin_amdgcn_sched_barrier(0);
             process_store(d1, off);
             off += step;
             if (off >= body_bytes) break;

@@ -79,7 +79,7 @@ struct Plan {
     uint32_t grid;
 };
 
-constexpr uint32_t kLargeGrid = 512u;        // two 1024-thread workgroups per CU (8 waves/SIMD), persistent
+constexpr uint32_t kLargeGrid = 256u;        // one persistent 1024-thread workgroup per CU (4 waves/SIMD)
 constexpr uint32_t kSmallGridMax = 16384u;   // 4 KiB chunks: grid * 1 tile <= 65536
 constexpr uint64_t kLargeMin = 8ull << 20;   // below this a one-shot small-chunk grid is used
 

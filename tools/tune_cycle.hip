@@ -23,9 +23,9 @@ struct Variant {
     std::vector<float> ms;
 };
 
-template <int U, int BLOCK, int ALG, bool PIPE, int MODE, int SAUX = 16> void launch(const CycleArgs &a, uint32_t grid, hipStream_t st)
+template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = 16, int SYNC = 0> void launch(const CycleArgs &a, uint32_t grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((modgpu_cycle_kernel<U, BLOCK, ALG, PIPE, MODE, SAUX>), dim3(grid), dim3(BLOCK), 0, st, a);
+    hipLaunchKernelGGL((modgpu_cycle_kernel<U, BLOCK, ALG, PIPE, MODE, SAUX, SYNC>), dim3(grid), dim3(BLOCK), 0, st, a);
 }
 
 int main(int argc, char **argv)
@@ -54,16 +54,23 @@ int main(int argc, char **argv)
         snprintf(b_, sizeof b_, "%-7s U=%d B=%4d alg=%d pipe=%d st=%2d grid=%5u", MODE == MODE_FULL ? "full" : MODE == MODE_COPY ? "copy" : "compute", U, B, ALG, (int)PIPE, SAUX, (unsigned)(g)); \
         vs.push_back({b_, launch<U, B, ALG, PIPE, MODE, SAUX>, (uint64_t)U * B * 16, (g), {}});               \
     } while (0)
+#define ADDY(U, B, ALG, PIPE, MODE, SYNC, g)                                                                  \
+    do {                                                                                                     \
+        char b_[128];                                                                                        \
+        snprintf(b_, sizeof b_, "%-7s U=%d B=%4d alg=%d pipe=%d sync=%d grid=%5u", MODE == MODE_FULL ? "full" : MODE == MODE_COPY ? "copy" : "compute", U, B, ALG, (int)PIPE, SYNC, (unsigned)(g)); \
+        vs.push_back({b_, launch<U, B, ALG, PIPE, MODE, 16, SYNC>, (uint64_t)U * B * 16, (g), {}});           \
+    } while (0)
     for (uint32_t g : {256u, 512u, 1024u}) {
-        ADDS(4, 1024, 1, true, MODE_FULL, 2, g);
-        ADDS(4, 1024, 1, true, MODE_FULL, 16, g);
-        ADDS(4, 1024, 0, true, MODE_FULL, 16, g);
-        ADDS(4, 1024, 0, false, MODE_FULL, 16, g);
-        ADDS(4, 1024, 1, false, MODE_FULL, 16, g);
-        ADDS(8, 1024, 1, false, MODE_FULL, 16, g);
-        ADDS(4, 1024, 1, true, MODE_COPY, 2, g);
-        ADDS(4, 1024, 1, true, MODE_COPY, 16, g);
-        ADDS(4, 1024, 1, false, MODE_COPY, 16, g);
+        ADDY(4, 1024, 1, 2, MODE_FULL, 0, g);
+        ADDY(4, 1024, 1, 2, MODE_FULL, 1, g);
+        ADDY(4, 1024, 1, 2, MODE_FULL, 2, g);
+        ADDY(4, 1024, 1, 2, MODE_FULL, 3, g);
+        ADDY(8, 1024, 1, 2, MODE_FULL, 0, g);
+        ADDY(8, 1024, 1, 2, MODE_FULL, 1, g);
+        ADDY(8, 1024, 1, 2, MODE_FULL, 3, g);
+        ADDY(4, 1024, 1, 2, MODE_COPY, 0, g);
+        ADDY(4, 1024, 1, 2, MODE_COPY, 1, g);
+        ADDY(8, 1024, 1, 2, MODE_COPY, 3, g);
     }
     CycleArgs a{};
     a.head_ptr = buf; a.head_n = 0; a.body = buf; a.body_words = n / 16; a.tail_ptr = buf + n; a.tail_n = 0;

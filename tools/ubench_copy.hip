@@ -180,6 +180,61 @@ __global__ __launch_bounds__(BLOCK) void mix_k(uint8_t *buf, uint64_t n_bytes)
     }
 }
 
+
+// block-synchronous phases: all waves of a workgroup issue their loads, barrier, then all stores
+template <int U, int BLOCK, int SYNC>
+__global__ __launch_bounds__(BLOCK) void phase_k(uint8_t *buf, uint64_t n_bytes)
+{
+    constexpr uint64_t TRIP = (uint64_t)U * BLOCK * 16;
+    const uint64_t trips = n_bytes / TRIP;
+    const uint32_t voff = threadIdx.x * 16;
+    uint64_t t = blockIdx.x;
+    if (t >= trips) return;
+    u32x4 cur[U], nxt[U];
+    {
+        auto r = __builtin_amdgcn_make_buffer_rsrc(buf + t * TRIP, 0, (int)TRIP, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * BLOCK * 16, 0, 2);
+    }
+    for (; t < trips; t += gridDim.x) {
+        uint64_t tn = t + gridDim.x;
+        auto rn = __builtin_amdgcn_make_buffer_rsrc(buf + tn * TRIP, 0, tn < trips ? (int)TRIP : 0, 0x00020000);
+        if (SYNC & 1) __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; ++u) nxt[u] = __builtin_amdgcn_raw_buffer_load_b128(rn, voff + u * BLOCK * 16, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (SYNC & 2) __builtin_amdgcn_s_barrier();
+        auto r = __builtin_amdgcn_make_buffer_rsrc(buf + t * TRIP, 0, (int)TRIP, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(~cur[u], r, voff + u * BLOCK * 16, 0, 16);
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
+}
+
+
+// non-pipelined block-synchronous bursts: barrier, U loads, barrier, U stores (two workgroups per CU interleave)
+template <int U, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void burst_k(uint8_t *buf, uint64_t n_bytes)
+{
+    constexpr uint64_t TRIP = (uint64_t)U * BLOCK * 16;
+    const uint64_t trips = n_bytes / TRIP;
+    const uint32_t voff = threadIdx.x * 16;
+    for (uint64_t t = blockIdx.x; t < trips; t += gridDim.x) {
+        auto r = __builtin_amdgcn_make_buffer_rsrc(buf + t * TRIP, 0, (int)TRIP, 0x00020000);
+        u32x4 d[U];
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * BLOCK * 16, 0, 2);
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = ~d[u];
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * BLOCK * 16, 0, 16);
+    }
+}
+
 struct V { std::string name; void (*fn)(uint8_t *, uint8_t *, uint64_t, uint32_t, hipStream_t); uint32_t grid; bool inplace; double bytes_factor; std::vector<float> ms; };
 
 template <int U, int BLOCK, int LA, int SA, bool CONTIG> void L(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st)
@@ -193,6 +248,10 @@ template <int U, int BLOCK, int AUX, bool WRITE> void LPOL(uint8_t *s, uint8_t *
 { hipLaunchKernelGGL((pol_k<U, BLOCK, AUX, WRITE>), dim3(g), dim3(BLOCK), 0, st, s, n, g_sink); }
 template <int U, int BLOCK, int LA, int SA, bool PIPE> void LMIX(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st)
 { hipLaunchKernelGGL((mix_k<U, BLOCK, LA, SA, PIPE>), dim3(g), dim3(BLOCK), 0, st, s, n); }
+template <int U, int BLOCK, int SYNC> void LPH(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st)
+{ hipLaunchKernelGGL((phase_k<U, BLOCK, SYNC>), dim3(g), dim3(BLOCK), 0, st, s, n); }
+template <int U, int BLOCK> void LBU(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st)
+{ hipLaunchKernelGGL((burst_k<U, BLOCK>), dim3(g), dim3(BLOCK), 0, st, s, n); }
 void LR(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st) { hipLaunchKernelGGL(read_k, dim3(g), dim3(256), 0, st, (const u32x4 *)s, n / 16, (uint32_t *)d); }
 void LW(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st) { hipLaunchKernelGGL(write_k, dim3(g), dim3(256), 0, st, (u32x4 *)s, n / 16); }
 void LM(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st) { (void)hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st); }
@@ -213,20 +272,17 @@ int main(int argc, char **argv)
         vs.push_back({buf, fn, g, inpl, f, {}});
     };
     CHECK(hipMalloc(&g_sink, 64));
-    for (uint32_t g : {256u, 512u, 768u, 1024u}) {
-        add("mix U4 ld=nt st=nt", LMIX<4, 1024, 2, 2, false>, g, true);
-        add("mix U4 ld=nt st=sc1", LMIX<4, 1024, 2, 16, false>, g, true);
-        add("mix U4 ld=nt st=sc0sc1", LMIX<4, 1024, 2, 17, false>, g, true);
-        add("mix U4 ld=nt st=0", LMIX<4, 1024, 2, 0, false>, g, true);
-        add("mix U4 ld=nt st=nt+sc1", LMIX<4, 1024, 2, 18, false>, g, true);
-        add("mix U4 ld=nt+sc1 st=sc1", LMIX<4, 1024, 18, 16, false>, g, true);
-        add("mix U4 ld=0 st=sc1", LMIX<4, 1024, 0, 16, false>, g, true);
-        add("mix U4 pipe ld=nt st=nt", LMIX<4, 1024, 2, 2, true>, g, true);
-        add("mix U4 pipe ld=nt st=sc1", LMIX<4, 1024, 2, 16, true>, g, true);
-        add("mix U4 pipe ld=nt st=0", LMIX<4, 1024, 2, 0, true>, g, true);
-        add("mix U8 ld=nt st=sc1", LMIX<8, 1024, 2, 16, false>, g, true);
-        add("mix U2 pipe ld=nt st=sc1", LMIX<2, 1024, 2, 16, true>, g, true);
-        add("mix U8 B512 ld=nt st=sc1", LMIX<8, 512, 2, 16, false>, g, true);
+    for (uint32_t g : {256u, 512u}) {
+        add("phase U8 both (pipelined)", LPH<8, 1024, 3>, g, true);
+        add("phase U6 both (pipelined)", LPH<6, 1024, 3>, g, true);
+        add("phase U12 both (pipelined)", LPH<12, 1024, 3>, g, true);
+        add("burst U4 B1024", LBU<4, 1024>, g, true);
+        add("burst U8 B1024", LBU<8, 1024>, g, true);
+        add("burst U12 B1024", LBU<12, 1024>, g, true);
+        add("burst U16 B1024", LBU<16, 1024>, g, true);
+        add("burst U24 B1024", LBU<24, 1024>, g, true);
+        add("burst U16 B512", LBU<16, 512>, g, true);
+        add("burst U32 B512", LBU<32, 512>, g, true);
     }
     for (int r = 0; r < rounds + 1; ++r)
         for (auto &v : vs) {
