@@ -8,11 +8,13 @@
 struct CycleArgs {
     void *body;          // 16-byte aligned start of the body
     uint64_t body_words; // full 16-byte words in the body
-    uint32_t base_body;  // state of the body's first byte
+    uint32_t base_body;  // state of the byte `lead` positions BEFORE the body's first byte (see lead)
     uint32_t stride_mul; // a^(chunk_bytes * gridDim): advances a lane-word by one grid trip
     uint8_t *head_ptr;   // first byte of the buffer (head_n < 16 bytes before the body)
     uint8_t *tail_ptr;   // first byte after the body (tail_n < 16 bytes)
     uint32_t head_n, tail_n;
+    uint32_t lead;       // body address modulo the variant's chunk size: chunks sit on absolute chunk-aligned
+                         // addresses, so the first one starts `lead` bytes before the body and is masked there
     uint32_t base_head;  // state of the buffer's first byte
     uint32_t base_tail;  // state of the first tail byte
 };

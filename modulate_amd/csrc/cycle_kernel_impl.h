@@ -137,14 +137,19 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
         }
     }
 
-    // ---- aligned body, chunk c = blk, blk + G, blk + 2G, ...
-    const uint64_t body_bytes = a.body_words * lcg::WORD;
+    // ---- aligned body.  Chunks sit on ABSOLUTE chunk-aligned addresses (a base that is only 16-byte
+    // aligned costs 15 % otherwise: every 1 KiB wave access would straddle 128-byte lines), so the
+    // chunk grid starts a.lead bytes before the body; offsets below are relative to that origin.
+    // Workgroup b takes chunks b, b + G, b + 2G, ...
+    const uint64_t lead = a.lead;
+    const uint64_t end = lead + a.body_words * lcg::WORD; // one past the body's last byte
     const uint64_t step = (uint64_t)gridDim.x * CHUNK;
     uint64_t off = (uint64_t)blk * CHUNK;
-    if (off >= body_bytes) return; // uniform for the workgroup
+    if (off >= end) return; // uniform for the workgroup
 
     // jump to this lane's first word: base * a^(4096*tile) * a^(16*(tid%256)),
-    // tile = blk*U*(BLOCK/256) + tid/256 < 65536 (host: grid * U * BLOCK/256 <= 65536)
+    // tile = blk*U*(BLOCK/256) + tid/256 < 65536 (host: grid * U * BLOCK/256 <= 65536);
+    // a.base_body already carries a^(-lead), so positions count from the chunk origin
     const uint32_t tile = blk * (U * (BLOCK / 256)) + (tid >> 8);
     uint32_t s[U];
     s[0] = mulmod_canon(a.base_body, c_tile_hi.v[(tile >> 8) & 255]);
@@ -153,27 +158,35 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
 #pragma unroll
     for (int u = 1; u < U; ++u) s[u] = mulmod_canon(s[u - 1], lcg::kTileLo.v[BLOCK / 256]);
 
-    uint8_t *const body = static_cast<uint8_t *>(a.body);
+    uint8_t *const origin = static_cast<uint8_t *>(a.body) - lead; // never dereferenced below the body
     const uint32_t voff = tid * lcg::WORD;
-    auto rsrc_at = [&](uint64_t o) {
-        uint64_t left = o < body_bytes ? body_bytes - o : 0;
-        return __builtin_amdgcn_make_buffer_rsrc(body + o, 0, (int)(left < CHUNK ? left : CHUNK), 0x00020000);
+    // Descriptor of the part of chunk [o, o + CHUNK) that lies inside the body, and `skip`, the
+    // bytes of the chunk in front of it (non-zero only for the first chunk).  Lanes in front get
+    // voffset - skip < 0, which wraps far past num_records: the hardware range check drops their
+    // loads (zeros) and stores, exactly as it does for lanes past the end of the last chunk.
+    auto rsrc_at = [&](uint64_t o, uint32_t &skip) {
+        uint64_t lo = o < lead ? lead : o;
+        uint64_t hi = o + CHUNK < end ? o + CHUNK : end;
+        skip = (uint32_t)(lo - o);
+        return __builtin_amdgcn_make_buffer_rsrc(origin + lo, 0, (int)(hi > lo ? hi - lo : 0), 0x00020000);
     };
     auto load = [&](u32x4(&d)[U], uint64_t o) {
-        auto r = rsrc_at(o);
+        uint32_t skip;
+        auto r = rsrc_at(o, skip);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if constexpr (MODE == MODE_COMPUTE) d[u] = u32x4{tid, blk, (uint32_t)o, (uint32_t)u};
-            else d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, AUX_NT);
+            else d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB - skip, 0, AUX_NT);
         }
     };
     auto process_store = [&](u32x4(&d)[U], uint64_t o) {
-        auto r = rsrc_at(o);
+        uint32_t skip;
+        auto r = rsrc_at(o, skip);
         if constexpr (PIPE == 3 && MODE == MODE_FULL) { // store each word as soon as it is done
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 d[u] = cycle_word<ALG>(d[u], s[u]);
-                __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
+                __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB - skip, 0, SAUX);
                 s[u] = mulmod_canon(s[u], a.stride_mul);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -195,13 +208,13 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
         for (int u = 0; u < U; ++u) {
             if constexpr (MODE == MODE_COMPUTE) {
                 if ((d[u].x ^ d[u].y ^ d[u].z ^ d[u].w) == 0x9E3779B9u && s[u] == 1u)
-                    __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
-            } else __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB - skip, 0, SAUX);
+            } else __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB - skip, 0, SAUX);
         }
     };
 
     if constexpr (PIPE == 0) {
-        for (; off < body_bytes; off += step) {
+        for (; off < end; off += step) {
             u32x4 d[U];
             load(d, off);
             process_store(d, off);
@@ -217,13 +230,13 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
             if constexpr (PIPE >= 2) __builtin_amdgcn_sched_barrier(0);
             process_store(d0, off);
             off += step;
-            if (off >= body_bytes) break;
+            if (off >= end) break;
             if constexpr (SYNC & 1) __builtin_amdgcn_s_barrier();
             load(d0, off + step);
             if constexpr (PIPE >= 2) __builtin_amdgcn_sched_barrier(0);
             process_store(d1, off);
             off += step;
-            if (off >= body_bytes) break;
+            if (off >= end) break;
         }
     }
 }

@@ -109,7 +109,11 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
     uint64_t body_bytes = words * 16;
     p.variant = body_bytes >= kLargeMin ? CYCLE_LARGE : CYCLE_SMALL;
     uint64_t chunk = modgpu_variant_chunk_bytes(p.variant);
-    uint64_t chunks = (body_bytes + chunk - 1) / chunk;
+    // chunks sit on absolute chunk-aligned addresses: the first starts `lead` bytes before the body,
+    // and the kernel counts positions from there, so its base state is stepped back by a^(-lead)
+    a.lead = (uint32_t)(reinterpret_cast<uintptr_t>(a.body) & (chunk - 1));
+    a.base_body = lcg::mulmod(a.base_body, lcg::powmod(lcg::A, lcg::PERIOD - a.lead % lcg::PERIOD));
+    uint64_t chunks = (a.lead + body_bytes + chunk - 1) / chunk;
     uint64_t cap = p.variant == CYCLE_LARGE ? kLargeGrid : kSmallGridMax;
     p.grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(chunks, cap));
     // one grid trip advances every lane-word by grid chunks

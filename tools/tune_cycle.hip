@@ -16,6 +16,7 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
 struct Variant {
+    uint32_t base_off = 0;
     std::string name;
     void (*launch)(const CycleArgs &, uint32_t grid, hipStream_t);
     uint64_t chunk;
@@ -46,38 +47,36 @@ int main(int argc, char **argv)
     do {                                                                                                     \
         char b_[128];                                                                                        \
         snprintf(b_, sizeof b_, "%-7s U=%d B=%4d alg=%d pipe=%d grid=%5u", MODE == MODE_FULL ? "full" : MODE == MODE_COPY ? "copy" : "compute", U, B, ALG, (int)PIPE, (unsigned)(g)); \
-        vs.push_back({b_, launch<U, B, ALG, PIPE, MODE>, (uint64_t)U * B * 16, (g), {}});                     \
+        vs.push_back({0, b_, launch<U, B, ALG, PIPE, MODE>, (uint64_t)U * B * 16, (g), {}});                     \
     } while (0)
 #define ADDS(U, B, ALG, PIPE, MODE, SAUX, g)                                                                  \
     do {                                                                                                     \
         char b_[128];                                                                                        \
         snprintf(b_, sizeof b_, "%-7s U=%d B=%4d alg=%d pipe=%d st=%2d grid=%5u", MODE == MODE_FULL ? "full" : MODE == MODE_COPY ? "copy" : "compute", U, B, ALG, (int)PIPE, SAUX, (unsigned)(g)); \
-        vs.push_back({b_, launch<U, B, ALG, PIPE, MODE, SAUX>, (uint64_t)U * B * 16, (g), {}});               \
+        vs.push_back({0, b_, launch<U, B, ALG, PIPE, MODE, SAUX>, (uint64_t)U * B * 16, (g), {}});               \
     } while (0)
 #define ADDY(U, B, ALG, PIPE, MODE, SYNC, g)                                                                  \
     do {                                                                                                     \
         char b_[128];                                                                                        \
         snprintf(b_, sizeof b_, "%-7s U=%d B=%4d alg=%d pipe=%d sync=%d grid=%5u", MODE == MODE_FULL ? "full" : MODE == MODE_COPY ? "copy" : "compute", U, B, ALG, (int)PIPE, SYNC, (unsigned)(g)); \
-        vs.push_back({b_, launch<U, B, ALG, PIPE, MODE, 16, SYNC>, (uint64_t)U * B * 16, (g), {}});           \
+        vs.push_back({0, b_, launch<U, B, ALG, PIPE, MODE, 16, SYNC>, (uint64_t)U * B * 16, (g), {}});           \
     } while (0)
-    for (uint32_t g : {256u, 512u, 1024u}) {
-        ADDY(4, 1024, 1, 2, MODE_FULL, 0, g);
-        ADDY(4, 1024, 1, 2, MODE_FULL, 1, g);
-        ADDY(4, 1024, 1, 2, MODE_FULL, 2, g);
-        ADDY(4, 1024, 1, 2, MODE_FULL, 3, g);
-        ADDY(8, 1024, 1, 2, MODE_FULL, 0, g);
-        ADDY(8, 1024, 1, 2, MODE_FULL, 1, g);
-        ADDY(8, 1024, 1, 2, MODE_FULL, 3, g);
-        ADDY(4, 1024, 1, 2, MODE_COPY, 0, g);
-        ADDY(4, 1024, 1, 2, MODE_COPY, 1, g);
-        ADDY(8, 1024, 1, 2, MODE_COPY, 3, g);
+    for (uint32_t off : {0u, 16u, 256u, 4096u, 65536u, 4096u + 16u}) {
+        ADDY(8, 1024, 1, 2, MODE_FULL, 3, 256u);
+        vs.back().base_off = off; vs.back().name += " base+" + std::to_string(off);
+        ADDY(8, 1024, 1, 2, MODE_COPY, 3, 256u);
+        vs.back().base_off = off; vs.back().name += " base+" + std::to_string(off);
     }
     CycleArgs a{};
-    a.head_ptr = buf; a.head_n = 0; a.body = buf; a.body_words = n / 16; a.tail_ptr = buf + n; a.tail_n = 0;
-    a.base_head = a.base_body = a.base_tail = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
+    a.head_ptr = buf; a.head_n = 0; a.body = buf; a.body_words = n / 16 - 8192; a.tail_ptr = buf + n; a.tail_n = 0; a.lead = 0;
+    const uint32_t base0 = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
+    a.base_head = a.base_body = a.base_tail = base0;
 
     for (int r = 0; r < rounds + 1; ++r) {
         for (auto &v : vs) {
+            a.body = buf + v.base_off;
+            a.lead = (uint32_t)((uintptr_t)a.body & (v.chunk - 1));
+            a.base_body = lcg::mulmod(base0, lcg::powmod(lcg::A, lcg::PERIOD - a.lead));
             a.stride_mul = lcg::powmod(lcg::A, ((uint64_t)v.grid * v.chunk) % lcg::PERIOD);
             CHECK(hipEventRecord(e0, st));
             v.launch(a, v.grid, st);
