@@ -160,33 +160,51 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
 
     uint8_t *const origin = static_cast<uint8_t *>(a.body) - lead; // never dereferenced below the body
     const uint32_t voff = tid * lcg::WORD;
-    // Descriptor of the part of chunk [o, o + CHUNK) that lies inside the body, and `skip`, the
-    // bytes of the chunk in front of it (non-zero only for the first chunk).  Lanes in front get
-    // voffset - skip < 0, which wraps far past num_records: the hardware range check drops their
-    // loads (zeros) and stores, exactly as it does for lanes past the end of the last chunk.
-    auto rsrc_at = [&](uint64_t o, uint32_t &skip) {
-        uint64_t lo = o < lead ? lead : o;
-        uint64_t hi = o + CHUNK < end ? o + CHUNK : end;
-        skip = (uint32_t)(lo - o);
-        return __builtin_amdgcn_make_buffer_rsrc(origin + lo, 0, (int)(hi > lo ? hi - lo : 0), 0x00020000);
+
+    // The first chunk is cut at the front when the body is not chunk-aligned.  Workgroup 0 peels it
+    // off here, outside the hot loop: descriptor based at the body, per-lane offset minus `lead`.
+    // Lanes in front of the body get a negative offset, which wraps far past num_records, so the
+    // hardware range check drops their loads (zeros) and stores -- the same mechanism that trims
+    // the last chunk.  Cold code: not unrolled.
+    if (blk == 0 && lead != 0) {
+        const uint64_t inside = end < CHUNK ? end - lead : CHUNK - lead;
+        auto r = __builtin_amdgcn_make_buffer_rsrc(static_cast<uint8_t *>(a.body), 0, (int)inside, 0x00020000);
+        uint32_t su = s[0];
+#pragma unroll 1
+        for (uint32_t u = 0; u < (uint32_t)U; ++u) {
+            const uint32_t o = voff + u * SUB - (uint32_t)lead;
+            u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, AUX_NT);
+            if constexpr (MODE == MODE_COPY) d = ~d;
+            else d = cycle_word<ALG>(d, su);
+            if constexpr (MODE != MODE_COMPUTE) __builtin_amdgcn_raw_buffer_store_b128(d, r, o, 0, SAUX);
+            su = mulmod_canon(su, lcg::kTileLo.v[BLOCK / 256]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) s[u] = mulmod_canon(s[u], a.stride_mul);
+        off += step;
+        if (off >= end) return;
+    }
+
+    // every remaining chunk starts inside the body; only the last can be short
+    auto rsrc_at = [&](uint64_t o) {
+        uint64_t left = o < end ? end - o : 0;
+        return __builtin_amdgcn_make_buffer_rsrc(origin + o, 0, (int)(left < CHUNK ? left : CHUNK), 0x00020000);
     };
     auto load = [&](u32x4(&d)[U], uint64_t o) {
-        uint32_t skip;
-        auto r = rsrc_at(o, skip);
+        auto r = rsrc_at(o);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if constexpr (MODE == MODE_COMPUTE) d[u] = u32x4{tid, blk, (uint32_t)o, (uint32_t)u};
-            else d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB - skip, 0, AUX_NT);
+            else d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, AUX_NT);
         }
     };
     auto process_store = [&](u32x4(&d)[U], uint64_t o) {
-        uint32_t skip;
-        auto r = rsrc_at(o, skip);
+        auto r = rsrc_at(o);
         if constexpr (PIPE == 3 && MODE == MODE_FULL) { // store each word as soon as it is done
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 d[u] = cycle_word<ALG>(d[u], s[u]);
-                __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB - skip, 0, SAUX);
+                __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
                 s[u] = mulmod_canon(s[u], a.stride_mul);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -208,8 +226,8 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
         for (int u = 0; u < U; ++u) {
             if constexpr (MODE == MODE_COMPUTE) {
                 if ((d[u].x ^ d[u].y ^ d[u].z ^ d[u].w) == 0x9E3779B9u && s[u] == 1u)
-                    __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB - skip, 0, SAUX);
-            } else __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB - skip, 0, SAUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
+            } else __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
         }
     };
 
