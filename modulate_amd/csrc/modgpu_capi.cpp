@@ -81,7 +81,10 @@ struct Plan {
 
 constexpr uint32_t kLargeGrid = 256u;        // one persistent 1024-thread workgroup per CU (4 waves/SIMD)
 constexpr uint32_t kSmallGridMax = 16384u;   // 4 KiB chunks: grid * 1 tile <= 65536
-constexpr uint64_t kLargeMin = 8ull << 20;   // below this a one-shot small-chunk grid is used
+// Hand-over between the two shapes, measured warm and cold (profiles/r01_tune_cycle_sizes*.txt):
+// up to 256 MiB the one-shot 4 KiB-chunk grid wins (launch cost ~3 us vs ~9 us, and the buffer fits
+// the 256 MiB Infinity Cache); beyond it the 128 KiB-burst streaming kernel does.
+constexpr uint64_t kLargeMin = (256ull << 20) + 1;
 
 // Splits [buf, buf+n) into <16 head bytes, an aligned body of 16-byte words and <16 tail bytes,
 // and computes the states that seed each piece.  key_res != 0.

@@ -141,6 +141,21 @@ def test_concurrent_host_calls(gpu, oracle):
         assert np.array_equal(res[i], oracle.cycle(pts[i].copy(), KEYS[i % len(KEYS)]))
 
 
+def test_mid_size_device_multi_trip(gpu, oracle):
+    """100 MiB + 77 on the device: the small-chunk shape grid-strides several trips here, and
+    300 MiB + 5: just past the hand-over to the streaming shape.  Misaligned bases, full compare."""
+    for n, base, key in (((100 << 20) + 77, 9, 0x90CFC0AB), ((300 << 20) + 5, 20, 0xC64EED30)):
+        pt = oracle.splitmix_bytes(n + 64, n)
+        dbuf = gpu.DeviceBuffer(n + 64)
+        dbuf.upload(pt)
+        dbuf.cycle(key, n=n, offset=base, stream_off=12345)
+        dbuf.sync()
+        want = pt.copy()
+        oracle.cycle_at(want[base:base + n], key, 12345)
+        assert np.array_equal(dbuf.download(), want), n
+        dbuf.free()
+
+
 def test_2g_boundary_device(gpu, oracle):
     """n = 2^31 + 4099 on the device (crosses the period P = 2^31-2 and the 2^31 index)."""
     n = (1 << 31) + 4099

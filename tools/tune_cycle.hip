@@ -33,8 +33,12 @@ int main(int argc, char **argv)
 {
     uint64_t n = argc > 1 ? strtoull(argv[1], nullptr, 0) : (1ull << 32);
     int rounds = argc > 2 ? atoi(argv[2]) : 5;
+    const bool cold = argc > 3 && atoi(argv[3]) != 0; // evict the buffer from the Infinity Cache before every launch
+    const int reps = cold ? 1 : (n >= (1ull << 30) ? 2 : 20);
+    uint8_t *scratch = nullptr;
+    if (cold) CHECK(hipMalloc(&scratch, 768ull << 20));
     uint8_t *buf;
-    CHECK(hipMalloc(&buf, n));
+    CHECK(hipMalloc(&buf, n + (1 << 20)));
     CHECK(hipMemset(buf, 0x5A, n));
     hipStream_t st;
     CHECK(hipStreamCreate(&st));
@@ -61,14 +65,20 @@ int main(int argc, char **argv)
         snprintf(b_, sizeof b_, "%-7s U=%d B=%4d alg=%d pipe=%d sync=%d grid=%5u", MODE == MODE_FULL ? "full" : MODE == MODE_COPY ? "copy" : "compute", U, B, ALG, (int)PIPE, SYNC, (unsigned)(g)); \
         vs.push_back({0, b_, launch<U, B, ALG, PIPE, MODE, 16, SYNC>, (uint64_t)U * B * 16, (g), {}});           \
     } while (0)
-    for (uint32_t off : {0u, 16u, 256u, 4096u, 65536u, 4096u + 16u}) {
-        ADDY(8, 1024, 1, 2, MODE_FULL, 3, 256u);
-        vs.back().base_off = off; vs.back().name += " base+" + std::to_string(off);
-        ADDY(8, 1024, 1, 2, MODE_COPY, 3, 256u);
-        vs.back().base_off = off; vs.back().name += " base+" + std::to_string(off);
-    }
+    auto autogrid = [&](uint64_t chunk, uint32_t cap) { return (uint32_t)std::min<uint64_t>((n + chunk - 1) / chunk, cap); };
+    ADDY(1, 256, 1, 0, MODE_FULL, 0, autogrid(4096, 16384));
+    ADDY(2, 256, 1, 0, MODE_FULL, 0, autogrid(8192, 8192));
+    ADDY(4, 256, 1, 0, MODE_FULL, 0, autogrid(16384, 4096));
+    ADDY(1, 1024, 1, 0, MODE_FULL, 0, autogrid(16384, 4096));
+    ADDY(2, 1024, 1, 0, MODE_FULL, 0, autogrid(32768, 2048));
+    ADDY(4, 1024, 1, 0, MODE_FULL, 0, autogrid(65536, 1024));
+    ADDY(4, 1024, 1, 0, MODE_FULL, 0, autogrid(65536, 512));
+    ADDY(4, 1024, 1, 0, MODE_FULL, 0, autogrid(65536, 256));
+    ADDY(4, 1024, 1, 2, MODE_FULL, 3, autogrid(65536, 256));
+    ADDY(8, 1024, 1, 0, MODE_FULL, 0, autogrid(131072, 256));
+    ADDY(8, 1024, 1, 2, MODE_FULL, 3, autogrid(131072, 256));
     CycleArgs a{};
-    a.head_ptr = buf; a.head_n = 0; a.body = buf; a.body_words = n / 16 - 8192; a.tail_ptr = buf + n; a.tail_n = 0; a.lead = 0;
+    a.head_ptr = buf; a.head_n = 0; a.body = buf; a.body_words = n / 16; a.tail_ptr = buf + n; a.tail_n = 0; a.lead = 0;
     const uint32_t base0 = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
     a.base_head = a.base_body = a.base_tail = base0;
 
@@ -78,18 +88,18 @@ int main(int argc, char **argv)
             a.lead = (uint32_t)((uintptr_t)a.body & (v.chunk - 1));
             a.base_body = lcg::mulmod(base0, lcg::powmod(lcg::A, lcg::PERIOD - a.lead));
             a.stride_mul = lcg::powmod(lcg::A, ((uint64_t)v.grid * v.chunk) % lcg::PERIOD);
+            if (cold) CHECK(hipMemsetAsync(scratch, r, 768ull << 20, st));
             CHECK(hipEventRecord(e0, st));
-            v.launch(a, v.grid, st);
-            v.launch(a, v.grid, st);
+            for (int k = 0; k < reps; ++k) v.launch(a, v.grid, st);
             CHECK(hipEventRecord(e1, st));
             CHECK(hipEventSynchronize(e1));
             float ms;
             CHECK(hipEventElapsedTime(&ms, e0, e1));
-            if (r > 0) v.ms.push_back(ms / 2);
+            if (r > 0) v.ms.push_back(ms / reps);
         }
     }
     CHECK(hipGetLastError());
-    printf("bytes=%llu rounds=%d  (GB/s = read+write = 2*bytes/t)\n", (unsigned long long)n, rounds);
+    printf("bytes=%llu rounds=%d cold=%d  (GB/s = read+write = 2*bytes/t)\n", (unsigned long long)n, rounds, (int)cold);
     for (auto &v : vs) {
         std::sort(v.ms.begin(), v.ms.end());
         float med = v.ms[v.ms.size() / 2], mn = v.ms.front();
