@@ -72,6 +72,11 @@ def main():
     ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: every rank uses this HIP device")
     a = ap.parse_args()
 
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so, libmodgpu.so binds to the
+    # same SONAME.  Whichever is loaded first serves both, so with several ranks torch (RCCL barrier)
+    # is imported BEFORE the product library is first used; with one rank torch is never imported.
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch  # noqa: F401
     import modulate_amd as M
     from modulate_amd import sharding
 

@@ -33,8 +33,16 @@ def dist_env():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def _single_process():
+    # torch is only imported when there really are several ranks: importing it after libmodgpu.so
+    # has loaded the system HIP runtime would bring torch's bundled copy in beside it (see bench.py)
+    return int(os.environ.get("WORLD_SIZE", "1")) <= 1
+
+
 def max_over_ranks(value, device=None):
     """MAX-reduce a python float over the default process group (identity when not initialised)."""
+    if _single_process():
+        return float(value)
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -45,6 +53,8 @@ def max_over_ranks(value, device=None):
 
 
 def sum_over_ranks(value, device=None):
+    if _single_process():
+        return float(value)
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
