@@ -70,12 +70,15 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier/MAX (nccl = RCCL); "
                     "gloo is for rehearsing N>1 on a box with fewer GPUs")
     ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: every rank uses this HIP device")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal only: initialise the process group even with one rank")
     a = ap.parse_args()
+    if a.force_dist:
+        os.environ["MODGPU_BENCH_FORCE_DIST"] = "1"
 
     # One HIP runtime per process: PyTorch bundles its own libamdhip64.so, libmodgpu.so binds to the
     # same SONAME.  Whichever is loaded first serves both, so with several ranks torch (RCCL barrier)
     # is imported BEFORE the product library is first used; with one rank torch is never imported.
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or a.force_dist:
         import torch  # noqa: F401
     import modulate_amd as M
     from modulate_amd import sharding
@@ -87,7 +90,7 @@ def main():
         a.gpus = world
     dist = None
     red_dev = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch
         import torch.distributed as dist
         if a.backend == "nccl":

@@ -36,7 +36,7 @@ def dist_env():
 def _single_process():
     # torch is only imported when there really are several ranks: importing it after libmodgpu.so
     # has loaded the system HIP runtime would bring torch's bundled copy in beside it (see bench.py)
-    return int(os.environ.get("WORLD_SIZE", "1")) <= 1
+    return int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not os.environ.get("MODGPU_BENCH_FORCE_DIST")
 
 
 def max_over_ranks(value, device=None):
