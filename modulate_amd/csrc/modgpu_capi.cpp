@@ -111,6 +111,13 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
 
     uint64_t body_bytes = words * 16;
     p.variant = body_bytes >= kLargeMin ? CYCLE_LARGE : CYCLE_SMALL;
+    // test / tuning knobs (read per call): MODGPU_FORCE_SHAPE=small|large picks the launch shape
+    // whatever the size, MODGPU_GRID caps the grid -- together they let the test-suite drive the
+    // streaming kernel through many trips and ragged ends on buffers of a few MiB.
+    if (const char *f = std::getenv("MODGPU_FORCE_SHAPE")) {
+        if (!std::strcmp(f, "large")) p.variant = CYCLE_LARGE;
+        else if (!std::strcmp(f, "small")) p.variant = CYCLE_SMALL;
+    }
     uint64_t chunk = modgpu_variant_chunk_bytes(p.variant);
     // chunks sit on absolute chunk-aligned addresses: the first starts `lead` bytes before the body,
     // and the kernel counts positions from there, so its base state is stepped back by a^(-lead)
@@ -118,6 +125,10 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
     a.base_body = lcg::mulmod(a.base_body, lcg::powmod(lcg::A, lcg::PERIOD - a.lead % lcg::PERIOD));
     uint64_t chunks = (a.lead + body_bytes + chunk - 1) / chunk;
     uint64_t cap = p.variant == CYCLE_LARGE ? kLargeGrid : kSmallGridMax;
+    if (const char *g = std::getenv("MODGPU_GRID")) {
+        long v = std::atol(g);
+        if (v >= 1 && (uint64_t)v < cap) cap = (uint64_t)v;
+    }
     p.grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(chunks, cap));
     // one grid trip advances every lane-word by grid chunks
     a.stride_mul = lcg::powmod(lcg::A, ((uint64_t)p.grid * chunk) % lcg::PERIOD);

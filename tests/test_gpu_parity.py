@@ -239,3 +239,46 @@ def test_config2_4gib_part_roundtrip(gpu, oracle, golden):
     for i, sd in enumerate(seeds):
         assert np.array_equal(dbuf.download(chunk, offset=i * chunk), oracle.splitmix_bytes(chunk, sd)), i
     dbuf.free()
+
+
+@pytest.mark.parametrize("shape,grid", [("large", 1), ("large", 2), ("large", 3), ("large", 7), ("large", None),
+                                        ("small", 1), ("small", 5), ("small", None)])
+def test_fuzz_forced_shapes(gpu, oracle, shape, grid):
+    """Randomised (size, misalignment, stream offset, key) against the oracle with the launch shape
+    and grid forced, so that the streaming kernel's pipelined loop sees 0, 1, 2, odd and even trip
+    counts, a masked first chunk and ragged last chunks on buffers of a few MiB."""
+    import os
+    rng = np.random.default_rng(hash((shape, grid)) & 0xFFFF)
+    old = {k: os.environ.get(k) for k in ("MODGPU_FORCE_SHAPE", "MODGPU_GRID")}
+    os.environ["MODGPU_FORCE_SHAPE"] = shape
+    if grid is None:
+        os.environ.pop("MODGPU_GRID", None)
+    else:
+        os.environ["MODGPU_GRID"] = str(grid)
+    try:
+        cap = (6 << 20) + 4096
+        dbuf = gpu.DeviceBuffer(cap)
+        chunk = 131072 if shape == "large" else 4096
+        sizes = [0, 1, 15, 16, 17, chunk - 16, chunk, chunk + 16, 2 * chunk, 2 * chunk + 5, 3 * chunk - 1, 5 * chunk + 123]
+        sizes += [int(x) for x in rng.integers(0, 6 << 20, size=14)]
+        for n in sizes:
+            base = int(rng.integers(0, 4096)) if n % 3 else int(rng.integers(0, 300000))
+            base = min(base, cap - n - 64)
+            key = [0x90CFC0AB, 0xC64EED30, int(rng.integers(1, 1 << 32))][n % 3]
+            so = [0, int(rng.integers(0, 1 << 40)), oracle.PERIOD - n // 2][n % 3]
+            whole = rng.integers(0, 256, size=n + 128, dtype=np.uint8)
+            lo = max(0, base - 64)
+            dbuf.upload(whole, offset=lo)
+            dbuf.cycle(key, n=n, offset=base, stream_off=so)
+            dbuf.sync()
+            got = dbuf.download(n + 128, offset=lo)
+            want = whole.copy()
+            oracle.cycle_at(want[base - lo:base - lo + n], key, so)
+            assert np.array_equal(got, want), (shape, grid, n, base, hex(key), so)
+        dbuf.free()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
