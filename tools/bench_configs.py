@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/bench_configs.py -- BASELINE configs 1, 4 and 5 plus the host-buffer (PCIe-inclusive) rate,
-timed end to end on one MI355X.  These are wall-clock pipeline numbers (disk = tmpfs), reported
+timed end to end on one MI355X (product code only: nothing under oracle/ is used here).  These are wall-clock pipeline numbers (disk = tmpfs), reported
 beside -- never instead of -- bench.py's HBM-resident kernel figure.
 
     python tools/bench_configs.py [--entries 100000] [--max-size 65536] [--arks 8] [--out gpurun_out/configs.json]
@@ -45,8 +45,6 @@ def main():
     a = ap.parse_args()
     import modulate_amd as M
     from modulate_amd import host as H
-    from oracle import oracle as O
-    from oracle import ark_header as AH
     assert M.device_count() >= 1
     res = {"entries": a.entries, "max_size": a.max_size, "arks": a.arks}
     rng = np.random.default_rng(0x4D6F6475)
@@ -68,7 +66,7 @@ def main():
     res["host_path"] = hp
 
     # ---- config 1: 4 KiB framed blob, decrypt (plumbing)
-    body = O.splitmix_bytes(4092, 1)
+    body = rng.integers(0, 256, size=4092, dtype=np.uint8)
     hdr = np.concatenate([np.zeros(4, np.uint8), body])
     M.hdr_encrypt_host(hdr, True)
     t0 = time.perf_counter()
@@ -106,13 +104,8 @@ def main():
         res["config4"] = {"payload_bytes": total, "header_bytes": int(img.size), "part_sizes": ark.ark_sizes(),
                           "seconds": dict(tm.t),
                           "parts_cycle_GBps": round(total / tm.t["c4_parts_cycle_gpu_hostpath"] / 1e9, 3)}
-        # spot parity: header vs Python restatement + oracle cipher; one part vs oracle
-        offs, parts = AH.split_into_arks(sizes, AH.even_plan(total, a.arks))
-        plain = np.frombuffer(AH.serialise(names, sizes, offs, parts, ark.ark_paths(), True), dtype=np.uint8).copy()
-        assert O.hdr_encrypt(plain, True) == 0
-        res["config4"]["header_matches_restatement"] = bool(np.array_equal(plain, img))
-        p0 = np.fromfile(first + ark.ark_paths()[0], dtype=np.uint8)
-        res["config4"]["part0_matches_oracle"] = bool(np.array_equal(p0[:1 << 24], O.cycle(data[:parts[0]][:1 << 24].copy(), O.KEY_PS4)))
+        # (parity of the header image and of the part cipher is asserted in tests/test_host_gpu.py;
+        #  this script only times, and checks the round trip below for self-consistency)
 
         # ---- config 5: decrypt -> unpack -> repack -> encrypt, byte-diff
         tm5 = T()
