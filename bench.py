@@ -165,7 +165,7 @@ def main():
         achieved = 2.0 * n / (ms_per_launch * 1e-3) / 1e9  # read + write per launch
         traffic = load_traffic(n)
         out = {
-            "metric": "GB/s encrypt+decrypt over synthetic .ark parts",
+            "metric": "GB/s encrypt+decrypt over synthetic .ark parts; % HBM peak at 1/2/4/8 GPU",
             "value": round(total_bytes / dt / 1e9, 2),
             "unit": "GB/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -235,6 +235,27 @@ __global__ __launch_bounds__(BLOCK) void burst_k(uint8_t *buf, uint64_t n_bytes)
     }
 }
 
+
+// read-only / write-only with workgroup-synchronous bursts
+template <int U, int BLOCK, int AUX, bool WRITE, bool SYNC>
+__global__ __launch_bounds__(BLOCK) void polb_k(uint8_t *buf, uint64_t n_bytes, uint32_t *sink)
+{
+    constexpr uint64_t TRIP = (uint64_t)U * BLOCK * 16;
+    const uint64_t trips = n_bytes / TRIP;
+    u32x4 acc = 0;
+    for (uint64_t t = blockIdx.x; t < trips; t += gridDim.x) {
+        auto r = __builtin_amdgcn_make_buffer_rsrc(buf + t * TRIP, 0, (int)TRIP, 0x00020000);
+        if (SYNC) __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t off = threadIdx.x * 16 + u * BLOCK * 16;
+            if (WRITE) __builtin_amdgcn_raw_buffer_store_b128(u32x4{(uint32_t)t, off, 1u, 2u}, r, off, 0, AUX);
+            else acc ^= __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX);
+        }
+    }
+    if (!WRITE && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345) sink[0] = 1;
+}
+
 struct V { std::string name; void (*fn)(uint8_t *, uint8_t *, uint64_t, uint32_t, hipStream_t); uint32_t grid; bool inplace; double bytes_factor; std::vector<float> ms; };
 
 template <int U, int BLOCK, int LA, int SA, bool CONTIG> void L(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st)
@@ -252,6 +273,8 @@ template <int U, int BLOCK, int SYNC> void LPH(uint8_t *s, uint8_t *d, uint64_t 
 { hipLaunchKernelGGL((phase_k<U, BLOCK, SYNC>), dim3(g), dim3(BLOCK), 0, st, s, n); }
 template <int U, int BLOCK> void LBU(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st)
 { hipLaunchKernelGGL((burst_k<U, BLOCK>), dim3(g), dim3(BLOCK), 0, st, s, n); }
+template <int U, int BLOCK, int AUX, bool WRITE, bool SYNC> void LPB(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st)
+{ hipLaunchKernelGGL((polb_k<U, BLOCK, AUX, WRITE, SYNC>), dim3(g), dim3(BLOCK), 0, st, s, n, g_sink); }
 void LR(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st) { hipLaunchKernelGGL(read_k, dim3(g), dim3(256), 0, st, (const u32x4 *)s, n / 16, (uint32_t *)d); }
 void LW(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st) { hipLaunchKernelGGL(write_k, dim3(g), dim3(256), 0, st, (u32x4 *)s, n / 16); }
 void LM(uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st) { (void)hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st); }
@@ -272,17 +295,21 @@ int main(int argc, char **argv)
         vs.push_back({buf, fn, g, inpl, f, {}});
     };
     CHECK(hipMalloc(&g_sink, 64));
-    for (uint32_t g : {256u, 512u}) {
-        add("phase U8 both (pipelined)", LPH<8, 1024, 3>, g, true);
-        add("phase U6 both (pipelined)", LPH<6, 1024, 3>, g, true);
-        add("phase U12 both (pipelined)", LPH<12, 1024, 3>, g, true);
-        add("burst U4 B1024", LBU<4, 1024>, g, true);
-        add("burst U8 B1024", LBU<8, 1024>, g, true);
-        add("burst U12 B1024", LBU<12, 1024>, g, true);
-        add("burst U16 B1024", LBU<16, 1024>, g, true);
-        add("burst U24 B1024", LBU<24, 1024>, g, true);
-        add("burst U16 B512", LBU<16, 512>, g, true);
-        add("burst U32 B512", LBU<32, 512>, g, true);
+    add("hipMemset (write ref)", [](uint8_t *s, uint8_t *d, uint64_t n, uint32_t g, hipStream_t st) { (void)hipMemsetAsync(s, 0x33, n, st); }, 0, true, 1.0);
+    for (uint32_t g : {256u, 512u, 1024u, 2048u}) {
+        add("write U4 sc1 nosync", LPB<4, 1024, 16, true, false>, g, true, 1.0);
+        add("write U4 sc1 sync", LPB<4, 1024, 16, true, true>, g, true, 1.0);
+        add("write U8 sc1 nosync", LPB<8, 1024, 16, true, false>, g, true, 1.0);
+        add("write U8 sc1 sync", LPB<8, 1024, 16, true, true>, g, true, 1.0);
+        add("write U8 plain sync", LPB<8, 1024, 0, true, true>, g, true, 1.0);
+        add("write U8 plain nosync", LPB<8, 1024, 0, true, false>, g, true, 1.0);
+        add("write U16 sc1 sync", LPB<16, 1024, 16, true, true>, g, true, 1.0);
+        add("write U2 sc1 sync", LPB<2, 1024, 16, true, true>, g, true, 1.0);
+        add("write U8 B256 plain", LPB<8, 256, 0, true, false>, g, true, 1.0);
+        add("read U4 nt nosync", LPB<4, 1024, 2, false, false>, g, true, 1.0);
+        add("read U4 nt sync", LPB<4, 1024, 2, false, true>, g, true, 1.0);
+        add("read U8 nt sync", LPB<8, 1024, 2, false, true>, g, true, 1.0);
+        add("read U2 nt sync", LPB<2, 1024, 2, false, true>, g, true, 1.0);
     }
     for (int r = 0; r < rounds + 1; ++r)
         for (auto &v : vs) {
