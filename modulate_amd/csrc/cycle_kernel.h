@@ -9,7 +9,8 @@ struct CycleArgs {
     void *body;          // 16-byte aligned start of the body
     uint64_t body_words; // full 16-byte words in the body
     uint32_t base_body;  // state of the byte `lead` positions BEFORE the body's first byte (see lead)
-    uint32_t stride_mul; // a^(chunk_bytes * gridDim): advances a lane-word by one grid trip
+    uint32_t stride_mul2; // 2 * a^(chunk_bytes * gridDim): advances a lane-word by one grid trip (pre-doubled
+                          // for the kernel's split-at-bit-32 multiply, see mul_fold)
     uint8_t *head_ptr;   // first byte of the buffer (head_n < 16 bytes before the body)
     uint8_t *tail_ptr;   // first byte after the body (tail_n < 16 bytes)
     uint32_t head_n, tail_n;

@@ -29,6 +29,13 @@ __device__ __forceinline__ uint32_t mul_fold(uint32_t s, uint32_t y2)
     return (uint32_t)(q >> 32);
 }
 
+// Same with the multiplier already doubled (y2 = 2*y < 2^32), e.g. a per-launch constant from the host.
+__device__ __forceinline__ uint32_t mulmod_canon2(uint32_t x, uint32_t y2)
+{
+    uint32_t X = mul_fold(x, y2);
+    return min(X, X - lcg::M);
+}
+
 // x canonical residue (< 2^31), y any residue < 2^31.  Returns x*y mod m, canonical.
 // X = x*y mod m or that + m, never m itself (m is prime, inputs non-zero), so min(X, X - m)
 // with unsigned wrap picks the canonical one.
@@ -44,8 +51,8 @@ __device__ __forceinline__ uint32_t mulmod_canon(uint32_t x, uint32_t y)
 template <int SEL> __device__ __forceinline__ void put_byte(uint32_t &w, uint32_t X)
 {
     uint32_t c = X >> 31; // the only possible excess over the canonical residue is m: +1 mod 256
-    if constexpr (SEL == 0)
-        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(X), "v"(c));
+    if constexpr (SEL == 0) // first byte of a dword: the other three are zero-filled, so `w` needs no initial value
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(w) : "v"(X), "v"(c));
     else if constexpr (SEL == 1)
         asm("v_add_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(X), "v"(c));
     else if constexpr (SEL == 2)
@@ -69,8 +76,9 @@ template <int J0, int ALG> __device__ __forceinline__ uint32_t ks_state_dword(ui
         return b0 | (lowbyte(state_x<J0 + 1>(s)) << 8) | (lowbyte(state_x<J0 + 2>(s)) << 16) |
                (lowbyte(state_x<J0 + 3>(s)) << 24);
     } else {
-        uint32_t w = s; // byte 0 of the first dword is the state itself; bytes 1..3 get overwritten
-        if constexpr (J0 != 0) put_byte<0>(w, state_x<(J0 == 0 ? 1 : J0)>(s));
+        uint32_t w;
+        if constexpr (J0 == 0) w = s; // byte 0 of the word is the lane state itself; bytes 1..3 get overwritten
+        else put_byte<0>(w, state_x<(J0 == 0 ? 1 : J0)>(s));
         put_byte<1>(w, state_x<J0 + 1>(s));
         put_byte<2>(w, state_x<J0 + 2>(s));
         put_byte<3>(w, state_x<J0 + 3>(s));
@@ -180,10 +188,15 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
             su = mulmod_canon(su, lcg::kTileLo.v[BLOCK / 256]);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) s[u] = mulmod_canon(s[u], a.stride_mul);
+        for (int u = 0; u < U; ++u) s[u] = mulmod_canon2(s[u], a.stride_mul2);
         off += step;
         if (off >= end) return;
     }
+
+    // (opaque copy: keeps the compiler from merging this 32-bit multiplier with the peel path's into
+    //  a 64-bit scalar pair, which cost one extra v_mad_u64_u32 per word in the hot loop)
+    uint32_t stride2 = a.stride_mul2;
+    asm("" : "+s"(stride2));
 
     // every remaining chunk starts inside the body; only the last can be short
     auto rsrc_at = [&](uint64_t o) {
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
             for (int u = 0; u < U; ++u) {
                 d[u] = cycle_word<ALG>(d[u], s[u]);
                 __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
-                s[u] = mulmod_canon(s[u], a.stride_mul);
+                s[u] = mulmod_canon2(s[u], stride2);
                 __builtin_amdgcn_sched_barrier(0);
             }
             return;
@@ -215,7 +228,7 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
             if constexpr (MODE == MODE_COPY) d[u] = ~d[u];
             else {
                 d[u] = cycle_word<ALG>(d[u], s[u]);
-                s[u] = mulmod_canon(s[u], a.stride_mul);
+                s[u] = mulmod_canon2(s[u], stride2);
             }
         }
         if constexpr ((SYNC & 2) != 0 && PIPE != 0) {

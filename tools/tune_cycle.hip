@@ -87,7 +87,7 @@ int main(int argc, char **argv)
             a.body = buf + v.base_off;
             a.lead = (uint32_t)((uintptr_t)a.body & (v.chunk - 1));
             a.base_body = lcg::mulmod(base0, lcg::powmod(lcg::A, lcg::PERIOD - a.lead));
-            a.stride_mul = lcg::powmod(lcg::A, ((uint64_t)v.grid * v.chunk) % lcg::PERIOD);
+            a.stride_mul2 = 2u * lcg::powmod(lcg::A, ((uint64_t)v.grid * v.chunk) % lcg::PERIOD);
             if (cold) CHECK(hipMemsetAsync(scratch, r, 768ull << 20, st));
             CHECK(hipEventRecord(e0, st));
             for (int k = 0; k < reps; ++k) v.launch(a, v.grid, st);
