@@ -12,7 +12,7 @@
  *     Modulate/CArk.cpp:1135-1136   CArk::SaveArk         (header encrypt)
  *     Modulate/Modulate.cpp:485-486 Decode                (-decode command)
  *
- * This header is what that class's body binds to (modulate_amd/csrc/CEncryptionCycler.cpp is
+ * This header is what that class's body binds to (modulate_amd/csrc/host/CEncryptionCycler.cpp is
  * the binding; INTEGRATION.md shows the same stub for the upstream tree).  Plain pointers and
  * sizes only; no C++ or torch types.  Every function returns MODGPU_OK (0) or a MODGPU_ERR_*
  * code, never throws, never prints; modgpu_last_error() gives the text for the calling thread.
@@ -47,6 +47,8 @@ extern "C" {
 #define MODGPU_ERR_HIP 3       /* a HIP runtime call failed; see modgpu_last_error()           */
 #define MODGPU_ERR_MAGIC 4     /* header magic is neither PS3 nor PS4 (eError_UnknownVersionNumber,
                                   Modulate/CArk.cpp:329-334, Modulate/Modulate.cpp:476-481)    */
+#define MODGPU_ERR_IO 5        /* open / read / write of a part file failed (eError_FailedToOpenFile,
+                                  eError_FailedToWriteData at Modulate/CArk.cpp:745-749, 883-889)     */
 
 /* Settings.h:16-20 */
 #define MODGPU_MAGIC_PS3 0xc64eed30u
@@ -55,7 +57,7 @@ extern "C" {
 #define MODGPU_KEY_PS4 0x90cfc0abu
 
 /* ABI version of this header (bumped on any signature change). */
-#define MODGPU_ABI_VERSION 1
+#define MODGPU_ABI_VERSION 2
 int modgpu_abi_version(void);
 
 /* Number of HIP devices visible to this process (0 if none / runtime unusable). */
@@ -91,6 +93,24 @@ int modgpu_hdr_encrypt_host(uint8_t *hdr, uint64_t size, int ps4, int device);
  * one host thread per GPU, no inter-GPU traffic.  n_devices <= 0 means all visible devices. */
 int modgpu_cycle_parts_host(uint8_t *const *parts, const uint64_t *sizes, int n_parts,
                             int32_t key, int n_devices);
+
+/* ---- part files streamed through the GPU ----------------------------
+ * The reference reads a part with one fread into the concatenated buffer (CArk.cpp:751) and writes
+ * a slice with one fwrite (CArk.cpp:883).  These do the same transfers with the cipher applied on
+ * the way, overlapped: pread -> pinned -> H2D -> kernel -> D2H -> pinned -> pwrite / caller memory,
+ * several chunks in flight, without a pageable staging copy.  Each call is one stream whose first
+ * byte has keystream position stream_off (0 = a part's own Cycle). */
+
+/* Whole file src_path -> dst_path (created / truncated).  The two may be the same path (in place). */
+int modgpu_cycle_file(const char *src_path, const char *dst_path, int32_t key, uint64_t stream_off, int device);
+
+/* n bytes at byte offset file_off of `path` -> host_dst[0..n). */
+int modgpu_cycle_file_to_host(const char *path, uint64_t file_off, uint8_t *host_dst, uint64_t n, int32_t key,
+                              uint64_t stream_off, int device);
+
+/* host_src[0..n) -> `path` (created / truncated).  host_src is not modified. */
+int modgpu_cycle_host_to_file(const uint8_t *host_src, uint64_t n, const char *path, int32_t key, uint64_t stream_off,
+                              int device);
 
 /* ---- thin device-memory helpers (bench / tests / callers that keep parts resident) --- */
 int modgpu_alloc(void **dev_ptr, uint64_t n, int device);

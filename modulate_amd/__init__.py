@@ -9,6 +9,6 @@ loudly if the HIP library has not been built.
 """
 from .capi import (  # noqa: F401
     ModGpuError, lib, lib_path, device_count, cycle_host, cycle_device, hdr_decrypt_host,
-    hdr_encrypt_host, cycle_parts_host, DeviceBuffer, time_cycle_device, state_at, jump_table,
+    hdr_encrypt_host, cycle_parts_host, cycle_file, cycle_file_to_host, cycle_host_to_file, DeviceBuffer, time_cycle_device, state_at, jump_table,
     KEY_PS3, KEY_PS4, MAGIC_PS3, MAGIC_PS4, as_int32, EXPORTS,
 )

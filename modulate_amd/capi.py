@@ -25,6 +25,9 @@ EXPORTS = {
     "modgpu_hdr_decrypt_host": (_int, [_vp, _u64, _int]),
     "modgpu_hdr_encrypt_host": (_int, [_vp, _u64, _int, _int]),
     "modgpu_cycle_parts_host": (_int, [ctypes.POINTER(_vp), ctypes.POINTER(_u64), _int, _i32, _int]),
+    "modgpu_cycle_file": (_int, [ctypes.c_char_p, ctypes.c_char_p, _i32, _u64, _int]),
+    "modgpu_cycle_file_to_host": (_int, [ctypes.c_char_p, _u64, _vp, _u64, _i32, _u64, _int]),
+    "modgpu_cycle_host_to_file": (_int, [_vp, _u64, ctypes.c_char_p, _i32, _u64, _int]),
     "modgpu_alloc": (_int, [ctypes.POINTER(_vp), _u64, _int]),
     "modgpu_free": (_int, [_vp, _int]),
     "modgpu_h2d": (_int, [_vp, _vp, _u64, _int]),
@@ -107,6 +110,24 @@ def cycle_parts_host(parts, key, n_devices=0):
     sizes = (_u64 * n)(*[p.size for p in parts])
     _check(lib().modgpu_cycle_parts_host(ptrs, sizes, n, as_int32(key), n_devices))
     return parts
+
+
+def cycle_file(src_path, dst_path, key, stream_off=0, device=-1):
+    """Stream a whole part file through the GPU (dst may equal src: in place)."""
+    _check(lib().modgpu_cycle_file(os.fsencode(src_path), os.fsencode(dst_path), as_int32(key), stream_off, device))
+
+
+def cycle_file_to_host(path, n, key, file_off=0, stream_off=0, device=-1):
+    out = np.empty(n, dtype=np.uint8)
+    _check(lib().modgpu_cycle_file_to_host(os.fsencode(path), file_off, _vp(out.ctypes.data), n, as_int32(key),
+                                           stream_off, device))
+    return out
+
+
+def cycle_host_to_file(buf, path, key, stream_off=0, device=-1):
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    _check(lib().modgpu_cycle_host_to_file(_vp(buf.ctypes.data), buf.size, os.fsencode(path), as_int32(key),
+                                           stream_off, device))
 
 
 def cycle_device(dev_ptr, n, key, stream_off=0, device=-1, stream=None):

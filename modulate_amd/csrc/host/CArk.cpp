@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <filesystem>
+#include <thread>
 #include <unordered_map>
 
 #include "../../../include/modgpu.h"
@@ -217,31 +218,74 @@ eError CArk::ParseHeader( std::vector< unsigned char > lImage )
 }
 
 // ------------------------------------------------------------------------------------ parts in
-eError CArk::LoadArkData() // CArk.cpp:723-758
+// Runs lWork( part index, device ) for every part, part i on GPU i mod N, one host thread per GPU
+// (no inter-GPU traffic: parts are independent streams).  Returns the first failure.
+template < typename F > static eError ForEachPartOnDevices( size_t liNumParts, int liNumDevices, F lWork )
 {
-    uint64_t luTotalArkSize = 0;
-    for( const sArkDefinition& a : maArks ) luTotalArkSize += a.muSize;
-    maArkData.assign( (size_t)luTotalArkSize, 0 );
-    char* lpArkPtr = maArkData.data();
-    for( const sArkDefinition& a : maArks )
+    int liAvailable = modgpu_device_count();
+    if( liAvailable <= 0 )
     {
-        FILE* f = std::fopen( a.mPath.c_str(), "rb" ); // as the reference: relative to the working directory
-        if( !f ) f = std::fopen( ( mHeaderDirectory + a.mPath ).c_str(), "rb" );
-        if( !f ) { eError leError = eError_FailedToOpenFile; SHOW_ERROR_AND_RETURN; }
-        size_t got = a.muSize ? std::fread( lpArkPtr, 1, a.muSize, f ) : 0;
-        std::fclose( f );
-        if( got != a.muSize ) { eError leError = eError_InvalidData; SHOW_ERROR_AND_RETURN; } // the reference does not check (CArk.cpp:751)
-        lpArkPtr += a.muSize;
+        std::printf( "ERROR: GPU part cipher failed: no HIP device visible\n" );
+        return eError_InvalidData;
     }
-    if( mbPartCipher ) // addition: parts are ciphertext on disk
-    {
-        eError leError = CycleArkData( miLoadedKey ? miLoadedKey : (int)( CSettings::mbPS4 ? CSettings::kuEncryptedPS4Key : CSettings::kuEncryptedPS3Key ), miPartDevices );
-        SHOW_ERROR_AND_RETURN;
-    }
+    if( liNumDevices <= 0 || liNumDevices > liAvailable ) liNumDevices = liAvailable;
+    liNumDevices = (int)std::min< size_t >( (size_t)liNumDevices, std::max< size_t >( liNumParts, 1 ) );
+    std::vector< eError > lResults( (size_t)liNumDevices, eError_NoError );
+    std::vector< std::thread > lThreads;
+    for( int d = 0; d < liNumDevices; ++d )
+        lThreads.emplace_back( [ &, d ] {
+            for( size_t i = (size_t)d; i < liNumParts && lResults[ d ] == eError_NoError; i += (size_t)liNumDevices )
+                lResults[ d ] = lWork( i, d );
+        } );
+    for( std::thread& t : lThreads ) t.join();
+    for( eError e : lResults )
+        if( e != eError_NoError ) return e;
     return eError_NoError;
 }
 
-eError CArk::CycleArkData( int liKey, int liNumDevices ) const // addition: north_star part cipher
+eError CArk::LoadArkData() // CArk.cpp:723-758
+{
+    uint64_t luTotalArkSize = 0;
+    std::vector< uint64_t > lOffsets;
+    std::vector< std::string > lPaths;
+    for( const sArkDefinition& a : maArks )
+    {
+        lOffsets.push_back( luTotalArkSize );
+        luTotalArkSize += a.muSize;
+        // as the reference: relative to the working directory; else beside the header that was loaded
+        std::error_code ec;
+        lPaths.push_back( fs::exists( a.mPath, ec ) ? a.mPath : mHeaderDirectory + a.mPath );
+        if( !fs::is_regular_file( lPaths.back(), ec ) ) { eError leError = eError_FailedToOpenFile; SHOW_ERROR_AND_RETURN; }
+        if( fs::file_size( lPaths.back(), ec ) < a.muSize ) { eError leError = eError_InvalidData; SHOW_ERROR_AND_RETURN; } // the reference does not check (CArk.cpp:751)
+    }
+    maArkData.assign( (size_t)luTotalArkSize, 0 );
+    if( !mbPartCipher ) // the reference's behaviour: parts are stored raw
+    {
+        for( size_t ii = 0; ii < maArks.size(); ++ii )
+        {
+            FILE* f = std::fopen( lPaths[ ii ].c_str(), "rb" );
+            if( !f ) { eError leError = eError_FailedToOpenFile; SHOW_ERROR_AND_RETURN; }
+            size_t got = maArks[ ii ].muSize ? std::fread( maArkData.data() + lOffsets[ ii ], 1, maArks[ ii ].muSize, f ) : 0;
+            std::fclose( f );
+            if( got != maArks[ ii ].muSize ) { eError leError = eError_InvalidData; SHOW_ERROR_AND_RETURN; }
+        }
+        return eError_NoError;
+    }
+    // addition: parts are ciphertext on disk.  Each part file is streamed disk -> GPU -> its slice of
+    // the buffer (pread / H2D / kernel / D2H overlapped, modgpu_cycle_file_to_host), part i on GPU i mod N.
+    const int liKey = miLoadedKey ? miLoadedKey : (int)CSettings::Current().muKey;
+    eError leError = ForEachPartOnDevices( maArks.size(), miPartDevices, [ & ]( size_t ii, int liDevice ) {
+        int liStatus = modgpu_cycle_file_to_host( lPaths[ ii ].c_str(), 0, reinterpret_cast< uint8_t* >( maArkData.data() ) + lOffsets[ ii ],
+                                                  maArks[ ii ].muSize, liKey, 0, liDevice );
+        if( liStatus == MODGPU_OK ) return eError_NoError;
+        std::printf( "ERROR: part %s: %s\n", lPaths[ ii ].c_str(), modgpu_last_error() );
+        return liStatus == MODGPU_ERR_IO ? eError_FailedToOpenFile : eError_InvalidData;
+    } );
+    SHOW_ERROR_AND_RETURN;
+    return eError_NoError;
+}
+
+eError CArk::CycleArkData( int liKey, int liNumDevices ) // addition: north_star part cipher (in place, in memory)
 {
     std::vector< uint8_t* > lParts;
     std::vector< uint64_t > lSizes;
@@ -590,17 +634,8 @@ eError CArk::SaveArk( const char* lpOutputDirectory, const char* lpHeaderFilenam
     SHOW_ERROR_AND_RETURN;
 
     // part slices (lSaveArk, CArk.cpp:845-899)
-    const int liPartKey = (int)( CSettings::mbPS4 ? CSettings::kuEncryptedPS4Key : CSettings::kuEncryptedPS3Key );
-    if( mbPartCipher ) // addition: encrypt the slices for writing, restore them afterwards (involution)
-    {
-        leError = CycleArkData( liPartKey, miPartDevices );
-        SHOW_ERROR_AND_RETURN;
-    }
-    struct Restore
-    {
-        const CArk* mp; int miKey;
-        ~Restore() { if( mp ) mp->CycleArkData( miKey, mp->miPartDevices ); }
-    } lRestore{ mbPartCipher ? this : nullptr, liPartKey };
+    struct sJob { std::string mFilename; uint64_t muSlice; unsigned int muSize; };
+    std::vector< sJob > lJobs;
     uint64_t luOffset = 0;
     for( const sArkDefinition& a : maArks )
     {
@@ -617,14 +652,34 @@ eError CArk::SaveArk( const char* lpOutputDirectory, const char* lpHeaderFilenam
         std::error_code ec;
         fs::path lParent = fs::path( lFilename ).parent_path();
         if( !lParent.empty() ) fs::create_directories( lParent, ec );
-        leError = WriteWholeFile( lFilename, maArkData.data() + luSlice, a.muSize );
-        if( leError == eError_FailedToCreateFile )
-        {
-            std::printf( "Failed to open file for writing: %s\n", lFilename.c_str() );
-            leError = eError_NoError;
-            continue;
-        }
-        SHOW_ERROR_AND_RETURN;
+        lJobs.push_back( { lFilename, luSlice, a.muSize } );
     }
+    if( !mbPartCipher ) // the reference's behaviour: raw slices
+    {
+        for( const sJob& j : lJobs )
+        {
+            leError = WriteWholeFile( j.mFilename, maArkData.data() + j.muSlice, j.muSize );
+            if( leError == eError_FailedToCreateFile )
+            {
+                std::printf( "Failed to open file for writing: %s\n", j.mFilename.c_str() );
+                leError = eError_NoError;
+                continue;
+            }
+            SHOW_ERROR_AND_RETURN;
+        }
+        return eError_NoError;
+    }
+    // addition: each slice is streamed memory -> GPU -> file (H2D / kernel / D2H / pwrite overlapped,
+    // modgpu_cycle_host_to_file); the in-memory buffer is left untouched.  Part i on GPU i mod N.
+    const int liPartKey = (int)CSettings::Current().muKey; // on save the key follows the platform switch
+    leError = ForEachPartOnDevices( lJobs.size(), miPartDevices, [ & ]( size_t ii, int liDevice ) {
+        const sJob& j = lJobs[ ii ];
+        int liStatus = modgpu_cycle_host_to_file( reinterpret_cast< const uint8_t* >( maArkData.data() ) + j.muSlice, j.muSize,
+                                                  j.mFilename.c_str(), liPartKey, 0, liDevice );
+        if( liStatus == MODGPU_OK ) return eError_NoError;
+        std::printf( "ERROR: part %s: %s\n", j.mFilename.c_str(), modgpu_last_error() );
+        return liStatus == MODGPU_ERR_IO ? eError_FailedToWriteData : eError_InvalidData;
+    } );
+    SHOW_ERROR_AND_RETURN;
     return eError_NoError;
 }

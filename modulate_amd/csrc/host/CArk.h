@@ -51,9 +51,10 @@ public:
     // Part-level cipher (BASELINE.json north_star; the reference stores parts raw):
     // every part slice of the concatenated buffer is cycled in place as its own stream from
     // offset 0, part i on GPU i mod liNumDevices (<= 0: all visible), no inter-GPU traffic.
-    eError CycleArkData( int liKey, int liNumDevices = 0 ) const;
-    // When enabled, parts are ciphertext on disk: LoadArkData decrypts them after reading (key by the
-    // loaded header's magic) and SaveArk encrypts them for writing (key by CSettings::mbPS4).
+    eError CycleArkData( int liKey, int liNumDevices = 0 );
+    // When enabled, parts are ciphertext on disk: LoadArkData streams each part file disk -> GPU -> buffer
+    // (key by the loaded header's magic) and SaveArk streams each slice buffer -> GPU -> file (key by
+    // CSettings::mbPS4), part i on GPU i mod N, transfers and kernel overlapped.
     // Off by default = the reference's behaviour (parts stored raw).
     void EnablePartCipher( bool lbEnable, int liNumDevices = 0 ) { mbPartCipher = lbEnable; miPartDevices = liNumDevices; }
 
@@ -103,7 +104,7 @@ private:
 
     std::vector< sArkDefinition > maArks;
     mutable std::vector< sFileDefinition > maFiles; // SaveArk rewrites miFlags1, as the reference does (CArk.cpp:1094)
-    mutable std::vector< char > maArkData;          // SaveArk encrypts part slices in place and restores them
+    std::vector< char > maArkData;
     bool mbPartCipher = false;
     int miPartDevices = 0;
     int miLoadedKey = 0;                            // key selected by the loaded header's magic

@@ -7,7 +7,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -203,9 +208,54 @@ int staging_reserve(Staging &s, int n_slots, uint64_t need)
     return MODGPU_OK;
 }
 
-// One pipeline: chunks first, first+stride, ... of the buffer through slots [slot0, slot0+2).
-int run_pipe(Staging &s, int slot0, uint8_t *host, uint64_t n, uint64_t chunk, uint64_t first, uint64_t stride,
-             int32_t key, uint64_t stream_off)
+// Where a stream's bytes come from / go to: caller memory, or a file read / written at offsets
+// (pread / pwrite: safe from several pipeline threads at once).
+struct Endpoint {
+    uint8_t *mem = nullptr; // if set, bytes live at mem[0..n)
+    int fd = -1;            // else file descriptor, bytes at file offset base + [0..n)
+    uint64_t base = 0;
+};
+
+int io_fail(const char *what)
+{
+    t_err = std::string(what) + ": " + std::strerror(errno);
+    return MODGPU_ERR_IO;
+}
+
+int fill_slot(const Endpoint &src, uint8_t *pinned, uint64_t off, uint64_t len)
+{
+    if (src.mem) {
+        std::memcpy(pinned, src.mem + off, len);
+        return MODGPU_OK;
+    }
+    for (uint64_t done = 0; done < len;) {
+        ssize_t r = ::pread(src.fd, pinned + done, len - done, (off_t)(src.base + off + done));
+        if (r < 0 && errno == EINTR) continue;
+        if (r < 0) return io_fail("pread");
+        if (r == 0) return fail(MODGPU_ERR_IO, "pread: unexpected end of file");
+        done += (uint64_t)r;
+    }
+    return MODGPU_OK;
+}
+
+int drain_slot(const Endpoint &dst, const uint8_t *pinned, uint64_t off, uint64_t len)
+{
+    if (dst.mem) {
+        std::memcpy(dst.mem + off, pinned, len);
+        return MODGPU_OK;
+    }
+    for (uint64_t done = 0; done < len;) {
+        ssize_t r = ::pwrite(dst.fd, pinned + done, len - done, (off_t)(dst.base + off + done));
+        if (r < 0 && errno == EINTR) continue;
+        if (r < 0) return io_fail("pwrite");
+        done += (uint64_t)r;
+    }
+    return MODGPU_OK;
+}
+
+// One pipeline: chunks first, first+stride, ... of the stream through slots [slot0, slot0+2).
+int run_pipe(Staging &s, int slot0, const Endpoint &src, const Endpoint &dst, uint64_t n, uint64_t chunk,
+             uint64_t first, uint64_t stride, int32_t key, uint64_t stream_off)
 {
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
     auto span = [&](uint64_t c, uint64_t *off, uint64_t *len) {
@@ -213,35 +263,39 @@ int run_pipe(Staging &s, int slot0, uint8_t *host, uint64_t n, uint64_t chunk, u
         *len = std::min<uint64_t>(chunk, n - *off);
     };
     uint64_t mine = first < n_chunks ? (n_chunks - first + stride - 1) / stride : 0;
+    int rc = MODGPU_OK;
     for (uint64_t i = 0; i < mine + kSlotsPerPipe; ++i) {
         int slot = slot0 + (int)(i % kSlotsPerPipe);
         if (i >= kSlotsPerPipe) { // drain the chunk that used this slot two trips ago
             uint64_t off, len;
             span(first + (i - kSlotsPerPipe) * stride, &off, &len);
             HIP_TRY(hipStreamSynchronize(s.stream[slot]));
-            std::memcpy(host + off, s.pinned[slot], len);
+            if (rc == MODGPU_OK) rc = drain_slot(dst, s.pinned[slot], off, len);
         }
-        if (i < mine) {
+        if (i < mine && rc == MODGPU_OK) {
             uint64_t off, len;
             span(first + i * stride, &off, &len);
-            std::memcpy(s.pinned[slot], host + off, len);
+            rc = fill_slot(src, s.pinned[slot], off, len);
+            if (rc) continue; // keep draining what is already in flight, then report
             HIP_TRY(hipMemcpyAsync(s.dev[slot], s.pinned[slot], len, hipMemcpyHostToDevice, s.stream[slot]));
-            int rc = cycle_device_impl(s.dev[slot], len, key, stream_off + off, s.stream[slot]);
-            if (rc) return rc;
+            rc = cycle_device_impl(s.dev[slot], len, key, stream_off + off, s.stream[slot]);
+            if (rc) continue;
             HIP_TRY(hipMemcpyAsync(s.pinned[slot], s.dev[slot], len, hipMemcpyDeviceToHost, s.stream[slot]));
         }
     }
-    return MODGPU_OK;
+    return rc;
 }
 
-int cycle_host_impl(uint8_t *host, uint64_t n, int32_t key, uint64_t stream_off, int device)
+// src -> pinned -> H2D -> kernel -> D2H -> pinned -> dst for n bytes, over 1..kPipes pipelines.
+int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t key, uint64_t stream_off, int device)
 {
     if (n == 0) return MODGPU_OK;
-    if (!host) return fail(MODGPU_ERR_INVALID, "null host buffer");
     int dev = 0;
     int rc = resolve_device(device, &dev);
     if (rc) return rc;
-    if (lcg::key_residue(key) == 0) return MODGPU_OK; // identity, as in the reference
+    // keys == 0 mod m give the identity: nothing to do in place, a plain copy otherwise
+    const bool identity = lcg::key_residue(key) == 0;
+    if (identity && src.mem && src.mem == dst.mem) return MODGPU_OK;
     if (dev >= kMaxDevices) return fail(MODGPU_ERR_INVALID, "device index beyond staging table");
     Staging &s = g_staging[dev];
     std::lock_guard<std::mutex> lock(s.mu);
@@ -254,7 +308,7 @@ int cycle_host_impl(uint8_t *host, uint64_t n, int32_t key, uint64_t stream_off,
     const int pipes = (int)std::min<uint64_t>((uint64_t)kPipes, (n_chunks + 1) / 2); // a pipeline is worth >= 2 chunks
     rc = staging_reserve(s, pipes * kSlotsPerPipe, chunk);
     if (rc) return rc;
-    if (pipes <= 1) return run_pipe(s, 0, host, n, chunk, 0, 1, key, stream_off);
+    if (pipes <= 1) return run_pipe(s, 0, src, dst, n, chunk, 0, 1, key, stream_off);
 
     std::vector<int> rcs(pipes, MODGPU_OK);
     std::vector<std::string> errs(pipes);
@@ -265,7 +319,7 @@ int cycle_host_impl(uint8_t *host, uint64_t n, int32_t key, uint64_t stream_off,
             errs[p] = "hipSetDevice in staging worker";
             return;
         }
-        rcs[p] = run_pipe(s, p * kSlotsPerPipe, host, n, chunk, (uint64_t)p, (uint64_t)pipes, key, stream_off);
+        rcs[p] = run_pipe(s, p * kSlotsPerPipe, src, dst, n, chunk, (uint64_t)p, (uint64_t)pipes, key, stream_off);
         if (rcs[p]) errs[p] = t_err;
     };
     for (int p = 1; p < pipes; ++p) workers.emplace_back(body, p);
@@ -278,6 +332,20 @@ int cycle_host_impl(uint8_t *host, uint64_t n, int32_t key, uint64_t stream_off,
         }
     return MODGPU_OK;
 }
+
+int cycle_host_impl(uint8_t *host, uint64_t n, int32_t key, uint64_t stream_off, int device)
+{
+    if (n == 0) return MODGPU_OK;
+    if (!host) return fail(MODGPU_ERR_INVALID, "null host buffer");
+    Endpoint e;
+    e.mem = host;
+    return stream_impl(e, e, n, key, stream_off, device);
+}
+
+struct Fd { // closes on scope exit
+    int fd = -1;
+    ~Fd() { if (fd >= 0) ::close(fd); }
+};
 
 uint32_t load_le32(const uint8_t *p)
 {
@@ -365,6 +433,52 @@ int modgpu_cycle_parts_host(uint8_t *const *parts, const uint64_t *sizes, int n_
             return rcs[d];
         }
     return MODGPU_OK;
+}
+
+int modgpu_cycle_file(const char *src_path, const char *dst_path, int32_t key, uint64_t stream_off, int device)
+{
+    if (!src_path || !dst_path) return fail(MODGPU_ERR_INVALID, "null path");
+    const bool in_place = std::strcmp(src_path, dst_path) == 0;
+    Fd in, out;
+    in.fd = ::open(src_path, in_place ? O_RDWR : O_RDONLY);
+    if (in.fd < 0) return io_fail(src_path);
+    struct stat st;
+    if (::fstat(in.fd, &st) != 0) return io_fail("fstat");
+    if (!in_place) {
+        out.fd = ::open(dst_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (out.fd < 0) return io_fail(dst_path);
+    }
+    Endpoint src, dst;
+    src.fd = in.fd;
+    dst.fd = in_place ? in.fd : out.fd;
+    return stream_impl(src, dst, (uint64_t)st.st_size, key, stream_off, device);
+}
+
+int modgpu_cycle_file_to_host(const char *path, uint64_t file_off, uint8_t *host_dst, uint64_t n, int32_t key,
+                              uint64_t stream_off, int device)
+{
+    if (!path || (n && !host_dst)) return fail(MODGPU_ERR_INVALID, "null path or buffer");
+    Fd in;
+    in.fd = ::open(path, O_RDONLY);
+    if (in.fd < 0) return io_fail(path);
+    Endpoint src, dst;
+    src.fd = in.fd;
+    src.base = file_off;
+    dst.mem = host_dst;
+    return stream_impl(src, dst, n, key, stream_off, device);
+}
+
+int modgpu_cycle_host_to_file(const uint8_t *host_src, uint64_t n, const char *path, int32_t key, uint64_t stream_off,
+                              int device)
+{
+    if (!path || (n && !host_src)) return fail(MODGPU_ERR_INVALID, "null path or buffer");
+    Fd out;
+    out.fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (out.fd < 0) return io_fail(path);
+    Endpoint src, dst;
+    src.mem = const_cast<uint8_t *>(host_src); // only read from
+    dst.fd = out.fd;
+    return stream_impl(src, dst, n, key, stream_off, device);
 }
 
 int modgpu_alloc(void **dev_ptr, uint64_t n, int device)

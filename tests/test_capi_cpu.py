@@ -18,7 +18,7 @@ def test_header_symbols_all_exported(modgpu):
     L = modgpu.lib()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.modgpu_abi_version() == 1
+    assert L.modgpu_abi_version() == 2
 
 
 def test_state_at_matches_oracle(modgpu, oracle):

@@ -282,3 +282,35 @@ def test_fuzz_forced_shapes(gpu, oracle, shape, grid):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_part_files_streamed_through_gpu(gpu, oracle, tmp_path):
+    """a part file read -> GPU -> written (modgpu_cycle_file / _file_to_host /
+    _host_to_file) equals the oracle's Cycle of the same bytes; in place, windowed, multi-pipeline."""
+    for n in (0, 1, 4097, (5 << 20) + 3, (70 << 20) + 11):
+        pt = oracle.splitmix_bytes(n, n + 3)
+        want = oracle.cycle(pt.copy(), oracle.KEY_PS4) if n else pt
+        src, dst = tmp_path / f"p{n}.ark", tmp_path / f"c{n}.ark"
+        pt.tofile(src)
+        gpu.cycle_file(src, dst, gpu.KEY_PS4)
+        assert np.array_equal(np.fromfile(dst, dtype=np.uint8), want), n
+        gpu.cycle_file(dst, dst, gpu.KEY_PS4)  # in place: decrypts back
+        assert np.array_equal(np.fromfile(dst, dtype=np.uint8), pt), n
+        assert np.array_equal(gpu.cycle_file_to_host(src, n, gpu.KEY_PS4), want)
+        gpu.cycle_host_to_file(pt, dst, gpu.KEY_PS4)
+        assert np.array_equal(np.fromfile(dst, dtype=np.uint8), want), n
+    # a window of a file with its own stream offset
+    n = (3 << 20) + 5
+    pt = oracle.splitmix_bytes(n, 1)
+    (tmp_path / "w.ark").write_bytes(pt.tobytes())
+    got = gpu.cycle_file_to_host(tmp_path / "w.ark", 1_000_003, gpu.KEY_PS3, file_off=70_001, stream_off=(1 << 33) + 9)
+    want = pt[70_001:70_001 + 1_000_003].copy()
+    oracle.cycle_at(want, oracle.KEY_PS3, (1 << 33) + 9)
+    assert np.array_equal(got, want)
+    # errors: missing file, short file
+    with pytest.raises(gpu.ModGpuError) as e:
+        gpu.cycle_file(tmp_path / "missing.ark", tmp_path / "x", gpu.KEY_PS4)
+    assert e.value.code == 5
+    with pytest.raises(gpu.ModGpuError) as e:
+        gpu.cycle_file_to_host(tmp_path / "w.ark", n + 10, gpu.KEY_PS4)
+    assert e.value.code == 5
