@@ -189,3 +189,15 @@ def test_config1_4k_dta_blob_decrypt_and_parse(host, oracle, modgpu):
         modgpu.hdr_decrypt_host(framed)
         out, dump = host.dta_roundtrip(framed[4:].tobytes())
         assert out == body.tobytes() and dump == DT.dump(tree)
+
+
+def test_cpp_callsites(host, oracle, tmp_path):
+    """The reference's three call shapes in C++ against this repo's headers (tests/cpp/callsite_parity.cpp)."""
+    src = os.path.join(ROOT, "tests", "cpp", "callsite_parity.cpp")
+    exe = str(tmp_path / "callsite_parity")
+    lib = os.path.join(ROOT, "modulate_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(lib, "csrc", "host"), "-I" + os.path.join(ROOT, "oracle"),
+                           src, "-o", exe, "-L" + lib, "-lmodulate_host", "-lmodgpu", "-L" + os.path.join(ROOT, "oracle"),
+                           "-loracle_cycle", "-Wl,-rpath," + lib, "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "CALLSITES_OK" in r.stdout, r.stdout + r.stderr
