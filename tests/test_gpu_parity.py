@@ -314,3 +314,18 @@ def test_part_files_streamed_through_gpu(gpu, oracle, tmp_path):
     with pytest.raises(gpu.ModGpuError) as e:
         gpu.cycle_file_to_host(tmp_path / "w.ark", n + 10, gpu.KEY_PS4)
     assert e.value.code == 5
+
+
+def test_host_api_beyond_4gib(gpu, oracle):
+    """modgpu_cycle_host with n > 2^32 in one call (64-bit lengths end to end through the staging
+    pipelines); checked on windows against the oracle's closed-form keystream."""
+    n = (1 << 32) + 4099
+    buf = np.zeros(n, dtype=np.uint8)
+    gpu.cycle_host(buf, 0xC64EED30, stream_off=5)
+    for off in (0, (16 << 20) - 7, (1 << 31) + 1, (1 << 32) - 4096, n - 70000):
+        ln = min(70000, n - off)
+        assert np.array_equal(buf[off:off + ln], oracle.keystream(0xC64EED30, ln, 5 + off)), off
+    # cheap whole-buffer property: the keystream has period P = 2^31 - 2
+    P = oracle.PERIOD
+    assert np.array_equal(buf[:1 << 26], buf[P:P + (1 << 26)])
+    assert np.array_equal(buf[P:2 * P - (1 << 20)][-(1 << 24):], buf[0:P - (1 << 20)][-(1 << 24):])
