@@ -84,7 +84,22 @@ struct Plan {
     uint32_t grid;
 };
 
-constexpr uint32_t kLargeGrid = 256u;        // one persistent 1024-thread workgroup per CU (4 waves/SIMD)
+// Streaming shape: one persistent 1024-thread workgroup per CU (4 waves/SIMD), so the grid is the
+// device's CU count (256 on MI355X), looked up once per device.
+uint32_t large_grid()
+{
+    static std::mutex mu;
+    static uint32_t cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256u;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = (uint32_t)std::min(n, 2048); // grid * 32 tiles must stay <= 65536
+    }
+    return cus[dev];
+}
 constexpr uint32_t kSmallGridMax = 16384u;   // 4 KiB chunks: grid * 1 tile <= 65536
 // Hand-over between the two shapes, measured warm and cold (profiles/r01_tune_cycle_sizes*.txt):
 // up to 256 MiB the one-shot 4 KiB-chunk grid wins (launch cost ~3 us vs ~9 us, and the buffer fits
@@ -129,7 +144,7 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
     a.lead = (uint32_t)(reinterpret_cast<uintptr_t>(a.body) & (chunk - 1));
     a.base_body = lcg::mulmod(a.base_body, lcg::powmod(lcg::A, lcg::PERIOD - a.lead % lcg::PERIOD));
     uint64_t chunks = (a.lead + body_bytes + chunk - 1) / chunk;
-    uint64_t cap = p.variant == CYCLE_LARGE ? kLargeGrid : kSmallGridMax;
+    uint64_t cap = p.variant == CYCLE_LARGE ? large_grid() : kSmallGridMax;
     if (const char *g = std::getenv("MODGPU_GRID")) {
         long v = std::atol(g);
         if (v >= 1 && (uint64_t)v < cap) cap = (uint64_t)v;
