@@ -201,3 +201,17 @@ def test_cpp_callsites(host, oracle, tmp_path):
                            "-loracle_cycle", "-Wl,-rpath," + lib, "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "CALLSITES_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_max_length_one_cycle_call_matches_reference_digest(host, oracle, golden):
+    """The longest buffer one reference Cycle call can take (unsigned int: 2^32-1 bytes), through the
+    reference's own seam, against the digest of the REFERENCE's 2^32-1-byte run (tests/golden, made by
+    oracle/make_golden.py --big from the compiled CEncryptionCycler.cpp): every one of the 4 294 967 295
+    bytes is covered."""
+    L = golden["large"]
+    n = L["n"]
+    assert n == (1 << 32) - 1
+    buf = np.zeros(n, dtype=np.uint8)
+    host.cycle_via_class(buf, L["key"])
+    assert f"{oracle.fnv1a64(buf):016x}" == L["fnv_all"]
+    assert buf[L["tail16"]["start"]:].tobytes().hex() == L["tail16"]["hex"]
