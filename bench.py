@@ -94,6 +94,10 @@ def main():
         import torch
         import torch.distributed as dist
         if a.backend == "nccl":
+            # one rank per GPU; if the launcher already narrowed each rank's visibility to one device
+            # (HIP_VISIBLE_DEVICES per rank), that device is index 0 for everybody
+            if torch.cuda.device_count() <= local_rank:
+                local_rank = 0
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             red_dev = torch.device("cuda", local_rank)
