@@ -260,7 +260,7 @@ def test_fuzz_forced_shapes(gpu, oracle, shape, grid):
         dbuf = gpu.DeviceBuffer(cap)
         chunk = 131072 if shape == "large" else 4096
         sizes = [0, 1, 15, 16, 17, chunk - 16, chunk, chunk + 16, 2 * chunk, 2 * chunk + 5, 3 * chunk - 1, 5 * chunk + 123]
-        sizes += [int(x) for x in rng.integers(0, 6 << 20, size=14)]
+        sizes += [int(x) for x in rng.integers(0, 6 << 20, size=int(os.environ.get("MODGPU_FUZZ_CASES", "14")))]
         for n in sizes:
             base = int(rng.integers(0, 4096)) if n % 3 else int(rng.integers(0, 300000))
             base = min(base, cap - n - 64)
