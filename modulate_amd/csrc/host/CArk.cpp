@@ -4,6 +4,7 @@
 #include "CArk.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstdio>
 #include <cstring>
@@ -117,6 +118,31 @@ std::string WithSlash( const char* lpDir )
     return s;
 }
 } // namespace
+
+// The reference walks its file table on one thread; the per-entry file I/O here is independent, so it is
+// spread over a few host threads (entries are claimed through an atomic cursor).  lWork returns an eError;
+// the first failure stops the walk.
+template < typename F > eError ParallelOverEntries( int liBegin, int liEnd, F lWork )
+{
+    const int liThreads = (int)std::min< int64_t >( std::max( 1u, std::min( 16u, std::thread::hardware_concurrency() ) ), std::max( 1, ( liEnd - liBegin ) / 64 ) );
+    std::atomic< int > lNext( liBegin );
+    std::atomic< int > lFirstError( (int)eError_NoError );
+    auto lBody = [ & ] {
+        for( ;; )
+        {
+            const int ii = lNext.fetch_add( 1 );
+            if( ii >= liEnd || lFirstError.load() != (int)eError_NoError ) return;
+            eError e = lWork( ii );
+            int liExpected = (int)eError_NoError;
+            if( e != eError_NoError ) lFirstError.compare_exchange_strong( liExpected, (int)e );
+        }
+    };
+    std::vector< std::thread > lThreads;
+    for( int t = 1; t < liThreads; ++t ) lThreads.emplace_back( lBody );
+    lBody();
+    for( std::thread& t : lThreads ) t.join();
+    return (eError)lFirstError.load();
+}
 
 CArk::CArk() = default;
 CArk::~CArk() = default;
@@ -318,28 +344,28 @@ eError CArk::ExtractFiles( int liFirstFileIndex, int liNumFiles, const char* lpT
     int liBegin = std::max( 0, liFirstFileIndex );
     int liEnd = (int)std::min< int64_t >( (int64_t)maFiles.size(), (int64_t)liBegin + std::max( 0, liNumFiles ) );
     const std::string lTarget = lpTargetDirectory ? lpTargetDirectory : "";
-    for( int ii = liBegin; ii < liEnd; ++ii )
-    {
+    leError = ParallelOverEntries( liBegin, liEnd, [ & ]( int ii ) -> eError {
         const sFileDefinition& f = maFiles[ ii ];
         const std::string lOutputPath = lTarget + f.mName;
         if( KeepExisting( lOutputPath ) )
         {
             VERBOSE_OUT( "Output file already exists, skipping: " << lOutputPath << "\n" );
-            continue;
+            return eError_NoError;
         }
         std::error_code ec;
         fs::path lParent = fs::path( lOutputPath ).parent_path();
         if( !lParent.empty() )
         {
-            fs::create_directories( lParent, ec );
-            if( !fs::is_directory( lParent, ec ) ) { leError = eError_FailedToCreateDirectory; SHOW_ERROR_AND_RETURN; }
+            fs::create_directories( lParent, ec ); // concurrent creators of one directory are fine: checked below
+            if( !fs::is_directory( lParent, ec ) ) return eError_FailedToCreateDirectory;
         }
-        if( (uint64_t)f.mi64Offset + (uint64_t)f.miSize > maArkData.size() ) { leError = eError_InvalidData; SHOW_ERROR_AND_RETURN; }
+        if( (uint64_t)f.mi64Offset + (uint64_t)f.miSize > maArkData.size() ) return eError_InvalidData;
         VERBOSE_OUT( "Writing file " << lOutputPath << "\n" );
         eError leWrite = WriteWholeFile( lOutputPath, maArkData.data() + f.mi64Offset, (size_t)f.miSize );
-        if( leWrite == eError_FailedToCreateFile ) { std::printf( "Failed to create %s\n", lOutputPath.c_str() ); continue; } // CArk.cpp:486-489
-        if( leWrite != eError_NoError ) return leWrite;
-    }
+        if( leWrite == eError_FailedToCreateFile ) { std::printf( "Failed to create %s\n", lOutputPath.c_str() ); return eError_NoError; } // CArk.cpp:486-489
+        return leWrite;
+    } );
+    SHOW_ERROR_AND_RETURN;
     return eError_NoError;
 }
 
@@ -492,15 +518,16 @@ eError CArk::BuildArk( const char* lpInputDirectory, std::vector< SSongConfig > 
     for( const sFileDefinition& f : maFiles ) luTotalArkSize += (uint64_t)f.miSize;
     maArkData.assign( (size_t)luTotalArkSize, 0 );
     const std::string lInput = WithSlash( lpInputDirectory );
-    for( const sFileDefinition& f : maFiles )
-    {
-        if( f.miSize == 0 ) continue;
+    leError = ParallelOverEntries( 0, (int)maFiles.size(), [ & ]( int ii ) -> eError {
+        const sFileDefinition& f = maFiles[ ii ];
+        if( f.miSize == 0 ) return eError_NoError;
         FILE* lpInputFile = std::fopen( ( lInput + f.mName ).c_str(), "rb" );
-        if( !lpInputFile ) { leError = eError_FailedToOpenFile; SHOW_ERROR_AND_RETURN; }
+        if( !lpInputFile ) return eError_FailedToOpenFile;
         size_t got = std::fread( maArkData.data() + f.mi64Offset, 1, (size_t)f.miSize, lpInputFile );
         std::fclose( lpInputFile );
-        if( got != (size_t)f.miSize ) { leError = eError_InvalidData; SHOW_ERROR_AND_RETURN; }
-    }
+        return got == (size_t)f.miSize ? eError_NoError : eError_InvalidData;
+    } );
+    SHOW_ERROR_AND_RETURN;
     VERBOSE_OUT( "Ark built\n" );
     return eError_NoError;
 }
