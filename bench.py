@@ -129,8 +129,11 @@ def main():
     # timed region: exactly `steps` steps = 2*steps launches, HIP events on the launch stream
     t0 = time.perf_counter()
     ms_per_launch = M.time_cycle_device(part.ptr, n, a.key, 0, dev, None, iters=2 * a.steps)
+    t_sync = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("MODGPU_BENCH_DEBUG"):
+        print(f"[rank {rank}] steps done+synced at {t_sync*1e3:.3f} ms, after trailing barrier {dt*1e3:.3f} ms", file=sys.stderr)
     dt = sharding.max_over_ranks(dt, red_dev)
     ms_per_launch = sharding.max_over_ranks(ms_per_launch, red_dev)
 
