@@ -192,6 +192,8 @@ int env_int(const char *name, int dflt, int lo, int hi)
 }
 const int kPipes = env_int("MODGPU_HOST_PIPES", 4, 1, kMaxPipes);
 const uint64_t kChunk = (uint64_t)env_int("MODGPU_HOST_CHUNK_MB", 16, 1, 256) << 20;
+// MODGPU_HOST_ZEROCOPY_KB: largest host buffer cycled in place in pinned memory by the kernel (0 = never)
+const uint64_t kZeroCopyMax = (uint64_t)env_int("MODGPU_HOST_ZEROCOPY_KB", 1024, 0, 1 << 20) << 10;
 
 struct Staging {
     std::mutex mu;
@@ -314,6 +316,22 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     if (dev >= kMaxDevices) return fail(MODGPU_ERR_INVALID, "device index beyond staging table");
     Staging &s = g_staging[dev];
     std::lock_guard<std::mutex> lock(s.mu);
+
+    // Header-sized buffers (what the reference's three call sites actually pass: <= 512 KiB): skip the two
+    // DMA submissions and let the kernel read and write the pinned staging buffer across PCIe itself
+    // (hipHostMalloc memory is device-visible).  One launch + one sync instead of copy + launch + copy.
+    if (n <= kZeroCopyMax && src.mem && dst.mem && !identity) {
+        rc = staging_reserve(s, 1, n);
+        if (rc) return rc;
+        void *mapped = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&mapped, s.pinned[0], 0));
+        std::memcpy(s.pinned[0], src.mem, n);
+        rc = cycle_device_impl(mapped, n, key, stream_off, s.stream[0]);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(s.stream[0]));
+        std::memcpy(dst.mem, s.pinned[0], n);
+        return MODGPU_OK;
+    }
 
     // slot size: the whole buffer if it is small, else ~n/16 between 4 MiB and the cap (measured:
     // 4 MiB slots are best at 64 MiB, 16 MiB slots from 1 GiB up; profiles/r01_sweep_hostpath.txt)
