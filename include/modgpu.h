@@ -24,8 +24,15 @@
  * the reference's `unsigned int` length cap (2^32-1) and lets one logical stream be split over
  * calls or devices.  Keys congruent to 0 mod 2^31-1 give the identity, as in the reference.
  *
- * There is NO CPU implementation behind these entry points: without a usable HIP device the
- * compute calls fail with MODGPU_ERR_NO_DEVICE / MODGPU_ERR_HIP.
+ * Which engine computes.  Every modgpu_cycle_* / modgpu_hdr_* entry point below runs the gfx950
+ * kernel and NOTHING ELSE: without a usable HIP device they fail with MODGPU_ERR_NO_DEVICE /
+ * MODGPU_ERR_HIP.  The two exceptions are named for what they are:
+ *     modgpu_cycle_scalar_host   the library's own host loop (never the GPU)
+ *     modgpu_cycle_auto_host     the reference's "Cycle cannot fail" contract: GPU, and the host
+ *                                loop only when no GPU is usable
+ * modgpu_path_stats() counts calls and bytes per engine, and MODGPU_REQUIRE_GPU=1 in the environment
+ * forbids the host loop altogether (both entry points then fail with MODGPU_ERR_FORBIDDEN instead of
+ * computing), so a test-suite or benchmark can prove which engine produced its bytes.
  *
  * Threading: callable concurrently from any number of host threads.  `device` selects the GPU
  * per call (-1 = the calling thread's current HIP device); no global "current device" is
@@ -49,6 +56,7 @@ extern "C" {
                                   Modulate/CArk.cpp:329-334, Modulate/Modulate.cpp:476-481)    */
 #define MODGPU_ERR_IO 5        /* open / read / write of a part file failed (eError_FailedToOpenFile,
                                   eError_FailedToWriteData at Modulate/CArk.cpp:745-749, 883-889)     */
+#define MODGPU_ERR_FORBIDDEN 6 /* the host loop was needed or asked for, and MODGPU_REQUIRE_GPU=1 forbids it */
 
 /* Settings.h:16-20 */
 #define MODGPU_MAGIC_PS3 0xc64eed30u
@@ -57,10 +65,13 @@ extern "C" {
 #define MODGPU_KEY_PS4 0x90cfc0abu
 
 /* ABI version of this header (bumped on any signature change). */
-#define MODGPU_ABI_VERSION 2
+#define MODGPU_ABI_VERSION 3
 int modgpu_abi_version(void);
 
-/* Number of HIP devices visible to this process (0 if none / runtime unusable). */
+/* Number of HIP devices this library addresses (0 if none / runtime unusable).  Normally the
+ * devices visible to the process; with MODGPU_DEVICE_ALIAS=N in the environment (a rehearsal
+ * switch for multi-GPU code on a box with fewer GPUs) it is N logical devices, logical device d
+ * running on physical device d mod <visible>, each with its own staging context and worker. */
 int modgpu_device_count(void);
 
 /* Text of the last error raised on the calling thread ("" if none).  Never NULL. */
@@ -75,10 +86,23 @@ const char *modgpu_last_error(void);
 int modgpu_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off,
                         int device, void *hip_stream);
 
-/* Replaces CEncryptionCycler::Cycle (CEncryptionCycler.cpp:4-14) for a caller-owned HOST buffer:
- * H2D -> kernel -> D2H through pinned staging owned by this library, chunked and overlapped.
- * Synchronous: on return host_buf holds the result.  Never retains or frees host_buf. */
+/* Replaces CEncryptionCycler::Cycle (CEncryptionCycler.cpp:4-14) for a caller-owned HOST buffer,
+ * on the GPU.  Pageable memory is staged (memcpy -> pinned -> H2D -> kernel -> D2H -> pinned ->
+ * memcpy, chunked and overlapped); memory from modgpu_host_alloc (or any other HIP-pinned range)
+ * is cycled where it lies, with no staging copy.  Synchronous: on return host_buf holds the
+ * result.  Never retains or frees host_buf. */
 int modgpu_cycle_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, int device);
+
+/* The library's own host loop for the same arithmetic (closed form of CEncryptionCycler.cpp:16-25,
+ * sixteen independent byte states like one GPU lane-word; threads for large buffers).  This is
+ * product code for hosts without a GPU -- it shares nothing with the test oracle under oracle/. */
+int modgpu_cycle_scalar_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off);
+
+/* What CEncryptionCycler::Cycle binds to.  The reference's Cycle returns void and cannot fail
+ * (CEncryptionCycler.cpp:4-14), so: modgpu_cycle_host when a GPU is usable; when none is visible,
+ * or the GPU attempt fails before it has touched host_buf, modgpu_cycle_scalar_host.  With
+ * MODGPU_REQUIRE_GPU=1 there is no second engine and the GPU error is returned. */
+int modgpu_cycle_auto_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, int device);
 
 /* Header framing of CArk::Load (CArk.cpp:328-339) and Decode (Modulate.cpp:475-486):
  * LE u32 magic at hdr[0..3] selects the key, the cipher covers hdr[4..size).  Host buffer. */
@@ -90,7 +114,7 @@ int modgpu_hdr_encrypt_host(uint8_t *hdr, uint64_t size, int ps4, int device);
 
 /* Part-level sharding beside CArk::LoadArkData / lSaveArk (CArk.cpp:723-758, 845-899): part i
  * is an independent stream (its own Cycle from offset 0) and goes to GPU  i mod n_devices,
- * one host thread per GPU, no inter-GPU traffic.  n_devices <= 0 means all visible devices. */
+ * one host thread per GPU, no inter-GPU traffic.  n_devices <= 0 means all devices. */
 int modgpu_cycle_parts_host(uint8_t *const *parts, const uint64_t *sizes, int n_parts,
                             int32_t key, int n_devices);
 
@@ -98,10 +122,12 @@ int modgpu_cycle_parts_host(uint8_t *const *parts, const uint64_t *sizes, int n_
  * The reference reads a part with one fread into the concatenated buffer (CArk.cpp:751) and writes
  * a slice with one fwrite (CArk.cpp:883).  These do the same transfers with the cipher applied on
  * the way, overlapped: pread -> pinned -> H2D -> kernel -> D2H -> pinned -> pwrite / caller memory,
- * several chunks in flight, without a pageable staging copy.  Each call is one stream whose first
- * byte has keystream position stream_off (0 = a part's own Cycle). */
+ * several chunks in flight, without a pageable staging copy (and with no host copy at all on the
+ * memory side when that memory is pinned).  Each call is one stream whose first byte has
+ * keystream position stream_off (0 = a part's own Cycle). */
 
-/* Whole file src_path -> dst_path (created / truncated).  The two may be the same path (in place). */
+/* Whole file src_path -> dst_path (created / truncated).  The two may name the same file, by any
+ * spelling (compared by device and inode): it is then cycled in place. */
 int modgpu_cycle_file(const char *src_path, const char *dst_path, int32_t key, uint64_t stream_off, int device);
 
 /* n bytes at byte offset file_off of `path` -> host_dst[0..n). */
@@ -112,18 +138,38 @@ int modgpu_cycle_file_to_host(const char *path, uint64_t file_off, uint8_t *host
 int modgpu_cycle_host_to_file(const uint8_t *host_src, uint64_t n, const char *path, int32_t key, uint64_t stream_off,
                               int device);
 
+/* ---- page-locked host memory -----------------------------------------------------------------
+ * Replaces the `new char[total]` of CArk::LoadArkData / BuildArk (CArk.cpp:738, 780) for callers
+ * that will cycle the buffer: the GPU's DMA engines and kernels reach these pages directly, so
+ * the host-buffer entry points above skip both staging copies for any range inside them.
+ * Without a GPU the memory is ordinary (64-byte aligned) and everything still works. */
+int modgpu_host_alloc(void **host_ptr, uint64_t n);
+int modgpu_host_free(void *host_ptr);
+/* 1 if [p, p+n) lies inside one page-locked, device-visible allocation, else 0. */
+int modgpu_host_is_pinned(const void *p, uint64_t n);
+
+/* ---- which engine ran ---------------------------------------------------------------------- */
+typedef struct modgpu_path_stats {
+    uint64_t gpu_calls;      /* host-buffer / file calls served by the kernel                    */
+    uint64_t gpu_bytes;      /* payload bytes those calls cycled                                 */
+    uint64_t gpu_launches;   /* kernel launches, modgpu_cycle_device included                    */
+    uint64_t scalar_calls;   /* calls served by the host loop (direct or through _auto_)         */
+    uint64_t scalar_bytes;
+    uint64_t staged_bytes;   /* of gpu_bytes: went through a pageable<->pinned memcpy            */
+    uint64_t direct_bytes;   /* of gpu_bytes: DMA'd or read straight from the caller's pinned pages */
+    uint64_t auto_fallbacks; /* modgpu_cycle_auto_host calls that ended on the host loop         */
+} modgpu_path_stats_t;
+/* Process-wide counters since load (or the last reset).  reset != 0 zeroes them after the read. */
+int modgpu_path_stats(modgpu_path_stats_t *out, int reset);
+/* 1 if MODGPU_REQUIRE_GPU=1 was set when the library was loaded. */
+int modgpu_gpu_required(void);
+
 /* ---- thin device-memory helpers (bench / tests / callers that keep parts resident) --- */
 int modgpu_alloc(void **dev_ptr, uint64_t n, int device);
 int modgpu_free(void *dev_ptr, int device);
 int modgpu_h2d(void *dev_dst, const void *host_src, uint64_t n, int device);
 int modgpu_d2h(void *host_dst, const void *dev_src, uint64_t n, int device);
 int modgpu_sync(int device, void *hip_stream);
-
-/* Runs `iters` back-to-back modgpu_cycle_device launches on `hip_stream` bracketed by HIP events
- * recorded on that same stream and returns the mean milliseconds per launch in *ms_per_launch
- * (an even `iters` leaves the buffer unchanged: the cipher is an involution). */
-int modgpu_time_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off,
-                             int device, void *hip_stream, int iters, float *ms_per_launch);
 
 /* ---- host-side jump-ahead arithmetic (exposed so it can be checked without a GPU) ---- */
 

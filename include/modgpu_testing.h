@@ -1,0 +1,55 @@
+/*
+ * modgpu_testing.h -- measurement and test hooks of libmodgpu.so.
+ *
+ * NOT part of the drop-in boundary (that is include/modgpu.h, the only header an integrator
+ * needs).  bench.py, tools/ and tests/ use these to time launches on the launch stream, to learn
+ * which kernel instantiation a launch used, and to drive the streaming kernel through odd trip
+ * counts on small buffers.  Nothing here changes results: every hook either reports or picks
+ * between launch shapes that compute the same bytes.
+ */
+#ifndef MODGPU_TESTING_H
+#define MODGPU_TESTING_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Runs `iters` back-to-back modgpu_cycle_device launches on `hip_stream` bracketed by HIP events
+ * recorded on that same stream and returns the mean milliseconds per launch in *ms_per_launch
+ * (an even `iters` leaves the buffer unchanged: the cipher is an involution). */
+int modgpu_time_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off,
+                             int device, void *hip_stream, int iters, float *ms_per_launch);
+
+/* The launch the calling thread made last (any entry point), as the library planned it. */
+typedef struct modgpu_launch_info {
+    const char *kernel;   /* the instantiation's name as rocprofv3 prints it, e.g.
+                             "modgpu_cycle_kernel<8, 1024, 1, 2, 0, 16, 3>"; static storage      */
+    int variant;          /* 0 = small shape, 1 = streaming shape, 2 = mid-size streaming shape   */
+    uint32_t grid;        /* workgroups                                                           */
+    uint32_t block;       /* threads per workgroup                                                */
+    uint32_t chunk_bytes; /* bytes one workgroup trip covers                                      */
+    uint64_t bytes;       /* n of that launch                                                     */
+} modgpu_launch_info_t;
+int modgpu_last_launch(modgpu_launch_info_t *out);
+
+/* Forces the launch shape of every later launch in this process (-1 = by size, the default) and
+ * caps the grid (0 = no cap).  Lets the parity tests run the streaming kernels with 1, 2, odd and
+ * even trip counts and ragged ends on buffers of a few MiB. */
+void modgpu_debug_set_launch(int variant, uint32_t grid_cap);
+
+/* How modgpu_cycle_host treats a pinned caller buffer: 0 = library default, 1 = DMA pipeline
+ * (H2D -> kernel in HBM -> D2H straight from / to the caller's pages), 2 = one kernel over PCIe on
+ * the pages themselves.  Both give the same bytes; tools/sweep_hostpath.py times them. */
+void modgpu_debug_set_pinned_mode(int mode);
+
+/* Identity of the device code this library carries: hex SHA-256 over the kernel sources it was
+ * built from (cycle_kernel_impl.h, cycle_kernel.hip, cycle_kernel.h, lcg.h), fixed at build time.
+ * profiles/pmc_summary.json records it so that counter figures are never replayed for other code. */
+const char *modgpu_kernel_source_hash(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MODGPU_TESTING_H */

@@ -4,11 +4,13 @@ The product is the C-ABI shared library ``libmodgpu.so`` (include/modgpu.h), bui
 ``modulate_amd/csrc`` with hipcc, plus the C++ host mirror of the reference surface
 (``CEncryptionCycler``, the ``CArk`` buffer path) in ``libmodulate_host.so``.  This Python
 package is only a ctypes binding over those libraries for the test-suite and ``bench.py``;
-there is no Python or CPU implementation of the cipher in it, and importing the bindings fails
-loudly if the HIP library has not been built.
+there is no Python implementation of the cipher in it, and importing the bindings fails loudly if
+the HIP library has not been built.  (The library's own host loop, for machines without a GPU, lives
+in libmodgpu.so itself: modgpu_cycle_scalar_host / modgpu_cycle_auto_host, include/modgpu.h.)
 """
 from .capi import (  # noqa: F401
     ModGpuError, lib, lib_path, device_count, cycle_host, cycle_device, hdr_decrypt_host,
     hdr_encrypt_host, cycle_parts_host, cycle_file, cycle_file_to_host, cycle_host_to_file, DeviceBuffer, time_cycle_device, state_at, jump_table,
-    KEY_PS3, KEY_PS4, MAGIC_PS3, MAGIC_PS4, as_int32, EXPORTS,
+    KEY_PS3, KEY_PS4, MAGIC_PS3, MAGIC_PS4, as_int32, EXPORTS, TESTING_EXPORTS, cycle_scalar_host, cycle_auto_host,
+    path_stats, gpu_required, last_launch, debug_set_launch, debug_set_pinned_mode, kernel_source_hash, PinnedBuffer,
 )

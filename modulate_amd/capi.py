@@ -33,9 +33,40 @@ EXPORTS = {
     "modgpu_h2d": (_int, [_vp, _vp, _u64, _int]),
     "modgpu_d2h": (_int, [_vp, _vp, _u64, _int]),
     "modgpu_sync": (_int, [_int, _vp]),
-    "modgpu_time_cycle_device": (_int, [_vp, _u64, _i32, _u64, _int, _vp, _int, ctypes.POINTER(ctypes.c_float)]),
     "modgpu_state_at": (ctypes.c_uint32, [_i32, _u64]),
     "modgpu_jump_table": (_int, [_int, ctypes.POINTER(ctypes.c_uint32), _int]),
+    "modgpu_cycle_scalar_host": (_int, [_vp, _u64, _i32, _u64]),
+    "modgpu_cycle_auto_host": (_int, [_vp, _u64, _i32, _u64, _int]),
+    "modgpu_host_alloc": (_int, [ctypes.POINTER(_vp), _u64]),
+    "modgpu_host_free": (_int, [_vp]),
+    "modgpu_host_is_pinned": (_int, [_vp, _u64]),
+    "modgpu_path_stats": (_int, [_vp, _int]),
+    "modgpu_gpu_required": (_int, []),
+}
+
+
+class PathStats(ctypes.Structure):
+    """modgpu_path_stats_t (include/modgpu.h)."""
+    _fields_ = [(k, _u64) for k in ("gpu_calls", "gpu_bytes", "gpu_launches", "scalar_calls", "scalar_bytes",
+                                    "staged_bytes", "direct_bytes", "auto_fallbacks")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class LaunchInfo(ctypes.Structure):
+    """modgpu_launch_info_t (include/modgpu_testing.h)."""
+    _fields_ = [("kernel", ctypes.c_char_p), ("variant", _int), ("grid", ctypes.c_uint32), ("block", ctypes.c_uint32),
+                ("chunk_bytes", ctypes.c_uint32), ("bytes", _u64)]
+
+
+# every symbol include/modgpu_testing.h declares (measurement / test hooks, not the drop-in boundary)
+TESTING_EXPORTS = {
+    "modgpu_time_cycle_device": (_int, [_vp, _u64, _i32, _u64, _int, _vp, _int, ctypes.POINTER(ctypes.c_float)]),
+    "modgpu_last_launch": (_int, [ctypes.POINTER(LaunchInfo)]),
+    "modgpu_debug_set_launch": (None, [_int, ctypes.c_uint32]),
+    "modgpu_debug_set_pinned_mode": (None, [_int]),
+    "modgpu_kernel_source_hash": (ctypes.c_char_p, []),
 }
 
 
@@ -60,7 +91,7 @@ def lib():
         if not os.path.exists(path):
             raise ModGpuError(-1, f"{path} not built: run `make -C modulate_amd/csrc` (there is no CPU fallback)")
         L = ctypes.CDLL(path)
-        for name, (res, args) in EXPORTS.items():
+        for name, (res, args) in list(EXPORTS.items()) + list(TESTING_EXPORTS.items()):
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
@@ -94,6 +125,78 @@ def cycle_host(buf, key, stream_off=0, device=-1):
     return buf
 
 
+def cycle_scalar_host(buf, key, stream_off=0):
+    """The library's own host loop (never the GPU)."""
+    _check(lib().modgpu_cycle_scalar_host(_host_ptr(buf), buf.size, as_int32(key), stream_off))
+    return buf
+
+
+def cycle_auto_host(buf, key, stream_off=0, device=-1):
+    """What CEncryptionCycler::Cycle binds to: the GPU, the host loop only when no GPU is usable."""
+    _check(lib().modgpu_cycle_auto_host(_host_ptr(buf), buf.size, as_int32(key), stream_off, device))
+    return buf
+
+
+def path_stats(reset=False):
+    st = PathStats()
+    _check(lib().modgpu_path_stats(ctypes.byref(st), 1 if reset else 0))
+    return st.as_dict()
+
+
+def gpu_required():
+    return bool(lib().modgpu_gpu_required())
+
+
+def last_launch():
+    info = LaunchInfo()
+    _check(lib().modgpu_last_launch(ctypes.byref(info)))
+    return {"kernel": info.kernel.decode(), "variant": info.variant, "grid": info.grid, "block": info.block,
+            "chunk_bytes": info.chunk_bytes, "bytes": info.bytes}
+
+
+SHAPES = {None: -1, "auto": -1, "small": 0, "large": 1}
+
+
+def debug_set_launch(shape=None, grid_cap=0):
+    """Test hook: force the launch shape ("small" / "large" / None = by size) and cap the grid."""
+    lib().modgpu_debug_set_launch(SHAPES[shape], grid_cap or 0)
+
+
+def debug_set_pinned_mode(mode=0):
+    """Test hook: 0 default, 1 DMA pipeline, 2 kernel over PCIe, for pinned caller buffers."""
+    lib().modgpu_debug_set_pinned_mode(mode)
+
+
+def kernel_source_hash():
+    return lib().modgpu_kernel_source_hash().decode()
+
+
+class PinnedBuffer:
+    """Host memory from modgpu_host_alloc, viewed as a numpy uint8 array (`.array`)."""
+
+    def __init__(self, nbytes):
+        p = _vp()
+        _check(lib().modgpu_host_alloc(ctypes.byref(p), nbytes))
+        self.ptr, self.nbytes = p.value, nbytes
+        self.array = np.ctypeslib.as_array(ctypes.cast(self.ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(max(nbytes, 1),))[:nbytes]
+
+    @property
+    def pinned(self):
+        return bool(lib().modgpu_host_is_pinned(_vp(self.ptr), self.nbytes))
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            _check(lib().modgpu_host_free(_vp(self.ptr)))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def hdr_decrypt_host(hdr, device=-1):
     _check(lib().modgpu_hdr_decrypt_host(_host_ptr(hdr), hdr.size, device))
     return hdr
@@ -117,8 +220,11 @@ def cycle_file(src_path, dst_path, key, stream_off=0, device=-1):
     _check(lib().modgpu_cycle_file(os.fsencode(src_path), os.fsencode(dst_path), as_int32(key), stream_off, device))
 
 
-def cycle_file_to_host(path, n, key, file_off=0, stream_off=0, device=-1):
-    out = np.empty(n, dtype=np.uint8)
+def cycle_file_to_host(path, n, key, file_off=0, stream_off=0, device=-1, out=None):
+    """n bytes of a part file through the GPU into host memory (`out`: a caller array, e.g. a view of a PinnedBuffer)."""
+    if out is None:
+        out = np.empty(n, dtype=np.uint8)
+    assert out.dtype == np.uint8 and out.size == n and out.flags["C_CONTIGUOUS"]
     _check(lib().modgpu_cycle_file_to_host(os.fsencode(path), file_off, _vp(out.ctypes.data), n, as_int32(key),
                                            stream_off, device))
     return out

@@ -26,7 +26,12 @@ enum CycleVariant : int {
     CYCLE_SMALL = 0, // 256 threads x 1 word : 4 KiB chunks, headers and other small buffers
     CYCLE_LARGE = 1, // 1024 threads x 8 words, software-pipelined, workgroup-synchronous bursts: 128 KiB chunks
 };
+constexpr int kCycleVariants = 2;
 uint32_t modgpu_variant_chunk_bytes(int variant);
+uint32_t modgpu_variant_block(int variant);
+// The instantiation's name as a profiler prints it ("modgpu_cycle_kernel<8, 1024, 1, 2, 0, 16, 3>"),
+// generated from the same template arguments the launch uses, so it cannot go stale.
+const char *modgpu_variant_kernel_name(int variant);
 
 // Returns hipGetLastError().
 hipError_t modgpu_launch_cycle(const CycleArgs &a, int variant, uint32_t grid, hipStream_t stream);

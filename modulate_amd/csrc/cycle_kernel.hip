@@ -24,16 +24,38 @@
 
 #include "cycle_kernel_impl.h"
 
-uint32_t modgpu_variant_chunk_bytes(int variant)
-{
-    return variant == CYCLE_LARGE ? 8u * 1024u * lcg::WORD : 1u * 256u * lcg::WORD;
-}
+#include <cstdio>
+
+namespace {
+// One launch shape = one instantiation; everything the host layer asks about a shape comes from here.
+template <int U, int BLOCK, int ALG, int PIPE, int SAUX, int SYNC> struct Shape {
+    static constexpr uint32_t chunk = (uint32_t)U * BLOCK * lcg::WORD;
+    static constexpr uint32_t block = BLOCK;
+    static void launch(const CycleArgs &a, uint32_t grid, hipStream_t stream)
+    {
+        hipLaunchKernelGGL((modgpu_cycle_kernel<U, BLOCK, ALG, PIPE, MODE_FULL, SAUX, SYNC>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    }
+    static const char *name()
+    {
+        static char buf[96];
+        static const int n = std::snprintf(buf, sizeof buf, "modgpu_cycle_kernel<%d, %d, %d, %d, %d, %d, %d>", U, BLOCK, ALG, PIPE, (int)MODE_FULL, SAUX, SYNC);
+        (void)n;
+        return buf;
+    }
+};
+// one word per thread, 256 threads, no pipeline: launch-latency-bound sizes
+using Small = Shape<1, 256, 1, 0, AUX_SC1, 0>;
+// U=8 words x 1024 threads, SDWA keystream, pipelined + loads-first, sc1 stores, workgroup-synchronous bursts
+using Large = Shape<8, 1024, 1, 2, AUX_SC1, 3>;
+} // namespace
+
+uint32_t modgpu_variant_chunk_bytes(int variant) { return variant == CYCLE_LARGE ? Large::chunk : Small::chunk; }
+uint32_t modgpu_variant_block(int variant) { return variant == CYCLE_LARGE ? Large::block : Small::block; }
+const char *modgpu_variant_kernel_name(int variant) { return variant == CYCLE_LARGE ? Large::name() : Small::name(); }
 
 hipError_t modgpu_launch_cycle(const CycleArgs &a, int variant, uint32_t grid, hipStream_t stream)
 {
-    if (variant == CYCLE_LARGE) // U=8 words x 1024 threads, SDWA keystream, pipelined + loads-first, sc1 stores, sync bursts
-        hipLaunchKernelGGL((modgpu_cycle_kernel<8, 1024, 1, 2, MODE_FULL, AUX_SC1, 3>), dim3(grid), dim3(1024), 0, stream, a);
-    else // one word per thread, 256 threads, no pipeline: launch-latency-bound sizes
-        hipLaunchKernelGGL((modgpu_cycle_kernel<1, 256, 1, 0, MODE_FULL>), dim3(grid), dim3(256), 0, stream, a);
+    if (variant == CYCLE_LARGE) Large::launch(a, grid, stream);
+    else Small::launch(a, grid, stream);
     return hipGetLastError();
 }

@@ -144,10 +144,30 @@ template < typename F > eError ParallelOverEntries( int liBegin, int liEnd, F lW
     return (eError)lFirstError.load();
 }
 
+CArkDataBuffer::~CArkDataBuffer() { Release(); }
+
+void CArkDataBuffer::Release()
+{
+    if( mpData ) modgpu_host_free( mpData );
+    mpData = nullptr;
+    muSize = 0;
+}
+
+bool CArkDataBuffer::Allocate( uint64_t luSize )
+{
+    Release();
+    void* lp = nullptr;
+    if( modgpu_host_alloc( &lp, luSize ) != MODGPU_OK ) return false;
+    mpData = static_cast< char* >( lp );
+    muSize = luSize;
+    return true;
+}
+
 CArk::CArk() = default;
 CArk::~CArk() = default;
 
 int CArk::GetNumFiles() const { return (int)maFiles.size(); }
+bool CArk::IsArkDataPinned() const { return maArkData.size() != 0 && modgpu_host_is_pinned( maArkData.data(), maArkData.size() ) != 0; }
 
 const CArk::sFileDefinition* CArk::GetFile( const std::string& lName ) const
 {
@@ -284,7 +304,7 @@ eError CArk::LoadArkData() // CArk.cpp:723-758
         if( !fs::is_regular_file( lPaths.back(), ec ) ) { eError leError = eError_FailedToOpenFile; SHOW_ERROR_AND_RETURN; }
         if( fs::file_size( lPaths.back(), ec ) < a.muSize ) { eError leError = eError_InvalidData; SHOW_ERROR_AND_RETURN; } // the reference does not check (CArk.cpp:751)
     }
-    maArkData.assign( (size_t)luTotalArkSize, 0 );
+    if( !maArkData.Allocate( luTotalArkSize ) ) { eError leError = eError_NoData; SHOW_ERROR_AND_RETURN; } // CArk.cpp:738
     if( !mbPartCipher ) // the reference's behaviour: parts are stored raw
     {
         for( size_t ii = 0; ii < maArks.size(); ++ii )
@@ -339,10 +359,14 @@ eError CArk::ExtractFiles( int liFirstFileIndex, int liNumFiles, const char* lpT
     if( maFiles.empty() ) return eError_NoData;
     eError leError = LoadArkData();
     SHOW_ERROR_AND_RETURN;
-    // The reference walks every entry whatever the two index arguments say (CArk.cpp:435); its
-    // only caller passes (0, GetNumFiles()).  Here the range is honoured, clamped.
-    int liBegin = std::max( 0, liFirstFileIndex );
-    int liEnd = (int)std::min< int64_t >( (int64_t)maFiles.size(), (int64_t)liBegin + std::max( 0, liNumFiles ) );
+    // The reference walks every entry whatever the two index arguments say (CArk.cpp:435; its only
+    // caller passes (0, GetNumFiles())) and so does this by default; -fixquirks honours the range, clamped.
+    int liBegin = 0, liEnd = (int)maFiles.size();
+    if( CSettings::mbFixReferenceQuirks )
+    {
+        liBegin = std::max( 0, liFirstFileIndex );
+        liEnd = (int)std::min< int64_t >( (int64_t)maFiles.size(), (int64_t)liBegin + std::max( 0, liNumFiles ) );
+    }
     const std::string lTarget = lpTargetDirectory ? lpTargetDirectory : "";
     leError = ParallelOverEntries( liBegin, liEnd, [ & ]( int ii ) -> eError {
         const sFileDefinition& f = maFiles[ ii ];
@@ -516,7 +540,7 @@ eError CArk::BuildArk( const char* lpInputDirectory, std::vector< SSongConfig > 
     SHOW_ERROR_AND_RETURN;
     uint64_t luTotalArkSize = 0;
     for( const sFileDefinition& f : maFiles ) luTotalArkSize += (uint64_t)f.miSize;
-    maArkData.assign( (size_t)luTotalArkSize, 0 );
+    if( !maArkData.Allocate( luTotalArkSize ) ) { leError = eError_NoData; SHOW_ERROR_AND_RETURN; } // CArk.cpp:780
     const std::string lInput = WithSlash( lpInputDirectory );
     leError = ParallelOverEntries( 0, (int)maFiles.size(), [ & ]( int ii ) -> eError {
         const sFileDefinition& f = maFiles[ ii ];
@@ -539,7 +563,8 @@ eError CArk::BuildArkFromMemory( const char* lpData, uint64_t luDataSize )
     if( luTotal != luDataSize || ( luDataSize && !lpData ) ) return eError_InvalidParameter;
     eError leError = SplitIntoArks();
     ERROR_RETURN;
-    maArkData.assign( lpData, lpData + luDataSize );
+    if( !maArkData.Allocate( luDataSize ) ) return eError_NoData;
+    if( luDataSize ) std::memcpy( maArkData.data(), lpData, (size_t)luDataSize );
     return eError_NoError;
 }
 
@@ -641,8 +666,14 @@ eError CArk::SaveArk( const char* lpOutputDirectory, const char* lpHeaderFilenam
 {
     if( !lpHeaderFilename ) return eError_InvalidParameter;
     const std::string lOutput = lpOutputDirectory ? lpOutputDirectory : "";
-    // (the reference first insists that lpHeaderFilename can be opened for reading in the working
-    //  directory, CArk.cpp:904-909, and never uses or closes that handle; not reproduced)
+    if( !CSettings::mbFixReferenceQuirks )
+    {
+        // the reference first insists that lpHeaderFilename can be opened for reading in the working
+        // directory (CArk.cpp:904-909; it never reads from that handle)
+        FILE* lpHeaderFile = std::fopen( lpHeaderFilename, "rb" );
+        if( !lpHeaderFile ) { eError leError = eError_FailedToOpenFile; SHOW_ERROR_AND_RETURN; }
+        std::fclose( lpHeaderFile );
+    }
     std::vector< unsigned char > lHeader;
     eError leError = SerialiseHeader( lHeader, true );
     SHOW_ERROR_AND_RETURN;
@@ -663,32 +694,38 @@ eError CArk::SaveArk( const char* lpOutputDirectory, const char* lpHeaderFilenam
     // part slices (lSaveArk, CArk.cpp:845-899)
     struct sJob { std::string mFilename; uint64_t muSlice; unsigned int muSize; };
     std::vector< sJob > lJobs;
-    uint64_t luOffset = 0;
+    uint64_t luPartStart = 0; // where a part's bytes are by the part sizes
+    uint64_t luArkPtr = 0;    // the reference's lpArkPtr: moves only past parts it wrote (CArk.cpp:851, 891)
     for( const sArkDefinition& a : maArks )
     {
         const std::string lFilename = lOutput + a.mPath;
-        const uint64_t luSlice = luOffset;
-        luOffset += a.muSize; // the reference forgets to advance past a skipped part (CArk.cpp:866); fixed
+        // reference: a part that is skipped or cannot be opened leaves lpArkPtr where it was, so the
+        // parts after it are written from the wrong slice (CArk.cpp:866, 883-891); -fixquirks uses the sizes
+        const uint64_t luSlice = CSettings::mbFixReferenceQuirks ? luPartStart : luArkPtr;
+        luPartStart += a.muSize;
         if( KeepExisting( lFilename ) )
         {
             std::printf( "Output file already exists: %s\n", lFilename.c_str() );
             continue;
         }
         if( luSlice + a.muSize > maArkData.size() ) { leError = eError_NoData; SHOW_ERROR_AND_RETURN; }
-        std::printf( "Writing %s\n", lFilename.c_str() );
         std::error_code ec;
+        std::printf( "%s %s\n", fs::exists( lFilename, ec ) ? "Overwriting" : "Writing", lFilename.c_str() ); // CArk.cpp:871-879
         fs::path lParent = fs::path( lFilename ).parent_path();
         if( !lParent.empty() ) fs::create_directories( lParent, ec );
         lJobs.push_back( { lFilename, luSlice, a.muSize } );
+        luArkPtr += a.muSize;
     }
     if( !mbPartCipher ) // the reference's behaviour: raw slices
     {
+        uint64_t luNotWritten = 0; // bytes of parts whose file could not be opened (reference mode: lpArkPtr stays behind)
         for( const sJob& j : lJobs )
         {
-            leError = WriteWholeFile( j.mFilename, maArkData.data() + j.muSlice, j.muSize );
+            leError = WriteWholeFile( j.mFilename, maArkData.data() + j.muSlice - luNotWritten, j.muSize );
             if( leError == eError_FailedToCreateFile )
             {
                 std::printf( "Failed to open file for writing: %s\n", j.mFilename.c_str() );
+                if( !CSettings::mbFixReferenceQuirks ) luNotWritten += j.muSize;
                 leError = eError_NoError;
                 continue;
             }

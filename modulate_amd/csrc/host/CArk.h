@@ -29,6 +29,28 @@ struct SSongConfig
     int miUnlockCount = -1;
 };
 
+// The concatenated part buffer (the reference's `char* mpArkData`, CArk.h:88, `new char[total]` at
+// CArk.cpp:738, 780).  Allocated through modgpu_host_alloc: page-locked and device-visible when a GPU
+// is present, so the part cipher DMAs straight from / to these pages (no staging copy); ordinary
+// memory otherwise.  Contents are uninitialised after Allocate, as after the reference's new[].
+class CArkDataBuffer
+{
+public:
+    CArkDataBuffer() = default;
+    ~CArkDataBuffer();
+    CArkDataBuffer( const CArkDataBuffer& ) = delete;
+    CArkDataBuffer& operator=( const CArkDataBuffer& ) = delete;
+    bool Allocate( uint64_t luSize ); // false: out of memory
+    void Release();
+    char* data() { return mpData; }
+    const char* data() const { return mpData; }
+    uint64_t size() const { return muSize; }
+
+private:
+    char* mpData = nullptr;
+    uint64_t muSize = 0;
+};
+
 class CArk
 {
 public:
@@ -79,6 +101,7 @@ public:
     int GetFileFlags1( int ii ) const { return maFiles[ ii ].miFlags1; }
     int GetFileFlags2( int ii ) const { return maFiles[ ii ].miFlags2; }
     const char* GetArkData() const { return maArkData.data(); }
+    bool IsArkDataPinned() const;
     uint64_t GetArkDataSize() const { return maArkData.size(); }
 
 private:
@@ -104,7 +127,7 @@ private:
 
     std::vector< sArkDefinition > maArks;
     mutable std::vector< sFileDefinition > maFiles; // SaveArk rewrites miFlags1, as the reference does (CArk.cpp:1094)
-    std::vector< char > maArkData;
+    CArkDataBuffer maArkData;
     bool mbPartCipher = false;
     int miPartDevices = 0;
     int miLoadedKey = 0;                            // key selected by the loaded header's magic

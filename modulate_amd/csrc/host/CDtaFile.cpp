@@ -1,5 +1,6 @@
 // CDtaFile.cpp -- see CDtaFile.h.  Bounds-checked where the reference walks raw pointers.
 #include "CDtaFile.h"
+#include "Settings.h"
 
 #include <cstdio>
 #include <cstring>
@@ -177,9 +178,10 @@ void CDtaFile::SaveToMemory( std::vector< unsigned char >& lOut ) const // CDtaF
     bool lbFirst = true;
     for( const SDtaNode& n : maTopLevel )
     {
-        // The reference writes top-level nodes back to back (CDtaFile.cpp:371-374), which its own
-        // Load cannot read back when there is more than one; the separator Load expects is written here.
-        if( !lbFirst )
+        // The reference writes top-level trees back to back (CDtaFile.cpp:371-374) -- the default here
+        // too, although its own Load cannot read that back when there are several; -fixquirks writes
+        // the separator Load expects between them (CDtaFile.cpp:95-96).
+        if( !lbFirst && CSettings::mbFixReferenceQuirks )
         {
             Put< int32_t >( lOut, n.miType );
             Put< int32_t >( lOut, 1 );

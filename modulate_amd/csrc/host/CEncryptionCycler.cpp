@@ -16,12 +16,14 @@ int CEncryptionCycler::GetDevice() { return t_device; }
 
 void CEncryptionCycler::Cycle( unsigned char* lpData, unsigned int liDataSize, int liInitialKey )
 {
-    // stream offset 0: every Cycle call restarts the keystream (CEncryptionCycler.cpp:7)
-    const int liStatus = modgpu_cycle_host( lpData, liDataSize, liInitialKey, 0, t_device );
+    // stream offset 0: every Cycle call restarts the keystream (CEncryptionCycler.cpp:7).
+    // _auto_: the GPU kernel, and the library's host loop only where no GPU is usable -- the
+    // reference's Cycle returns void and cannot fail.
+    const int liStatus = modgpu_cycle_auto_host( lpData, liDataSize, liInitialKey, 0, t_device );
     if( liStatus != MODGPU_OK )
     {
-        // The reference's Cycle returns void and cannot fail; failing silently (or quietly
-        // computing on the CPU) would hide a broken GPU path, so fail loudly instead.
+        // reachable only when MODGPU_REQUIRE_GPU=1 forbade the host loop, or a GPU died half-way
+        // through the buffer: failing silently would hand back bytes that are not the reference's
         throw std::runtime_error( std::string( "CEncryptionCycler::Cycle: GPU path failed: " ) + modgpu_last_error() );
     }
 }

@@ -13,8 +13,11 @@ class CEncryptionCycler
 {
 public:
     // In-place LCG-XOR of liDataSize bytes at lpData (a HOST pointer, any alignment), keystream
-    // restarted from liInitialKey -- bit-identical to the reference loop, computed on the MI355X.
-    // Throws std::runtime_error if the GPU path fails: there is no CPU loop to fall back to.
+    // restarted from liInitialKey -- bit-identical to the reference loop.  Computed on the MI355X;
+    // like the reference's, this Cycle cannot fail: on a host with no usable GPU the library's own
+    // host loop produces the same bytes (modgpu_cycle_auto_host).  The one exception is opt-in:
+    // with MODGPU_REQUIRE_GPU=1 in the environment a missing GPU throws std::runtime_error instead
+    // (test-suites and benchmarks set it so that nothing is ever measured on the wrong engine).
     void Cycle( unsigned char* lpData, unsigned int liDataSize, int liInitialKey );
 
     // Which GPU the calling thread's Cycle calls use (-1 = that thread's current HIP device).

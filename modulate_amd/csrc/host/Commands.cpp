@@ -2,6 +2,7 @@
 #include "Commands.h"
 
 #include <cstdio>
+#include <filesystem>
 #include <iostream>
 #include <vector>
 
@@ -17,6 +18,34 @@ std::string Slashed( std::string s )
     return s;
 }
 std::string HeaderName() { return std::string( "main_" ) + CSettings::msPlatform + ".hdr"; }
+
+// The reference works in the directory that holds main_<platform>.hdr (it opens the header, and
+// SaveArk re-opens it, by bare file name: Modulate.cpp:383-395, CArk.cpp:904-909).  These commands
+// take that directory as an argument instead; for the duration of a command it becomes the working
+// directory, so every bare-name open behaves as upstream.  Other paths are made absolute first.
+struct SWorkIn
+{
+    std::filesystem::path mPrevious;
+    bool mbOk = true;
+    explicit SWorkIn( const std::string& lDirectory )
+    {
+        std::error_code ec;
+        mPrevious = std::filesystem::current_path( ec );
+        if( !lDirectory.empty() ) std::filesystem::current_path( lDirectory, ec );
+        mbOk = !ec;
+    }
+    ~SWorkIn()
+    {
+        std::error_code ec;
+        std::filesystem::current_path( mPrevious, ec );
+    }
+};
+std::string Absolute( const std::string& lPath )
+{
+    std::error_code ec;
+    std::filesystem::path p = std::filesystem::absolute( lPath, ec );
+    return ec ? lPath : p.string();
+}
 } // namespace
 
 eError Decode( const std::string& lDirectory ) // Modulate.cpp:452-502
@@ -61,14 +90,17 @@ eError Unpack( const std::string& lHeaderDirectory, const std::string& lOutputDi
 eError Pack( const std::string& lHeaderDirectory, const std::string& lInputDirectory, const std::string& lOutputDirectory, bool lbCryptParts, int liNumDevices ) // Modulate.cpp:380-450
 {
     std::cout << "Packing " << HeaderName() << " from " << lInputDirectory << " to " << lOutputDirectory << "\n";
+    const std::string lInput = Slashed( Absolute( lInputDirectory ) ), lOutput = Slashed( Absolute( lOutputDirectory ) );
+    SWorkIn lWorkIn( lHeaderDirectory );
+    if( !lWorkIn.mbOk ) return eError_FailedToOpenFile;
     CArk lReferenceArkHeader;
-    eError leError = lReferenceArkHeader.Load( ( Slashed( lHeaderDirectory ) + HeaderName() ).c_str() );
+    eError leError = lReferenceArkHeader.Load( HeaderName().c_str() );
     SHOW_ERROR_AND_RETURN;
     CArk lArkHeader;
-    leError = lArkHeader.ConstructFromDirectory( Slashed( lInputDirectory ).c_str(), lReferenceArkHeader, {} );
+    leError = lArkHeader.ConstructFromDirectory( lInput.c_str(), lReferenceArkHeader, {} );
     SHOW_ERROR_AND_RETURN;
-    leError = lArkHeader.BuildArk( Slashed( lInputDirectory ).c_str(), {} );
+    leError = lArkHeader.BuildArk( lInput.c_str(), {} );
     SHOW_ERROR_AND_RETURN; // (the reference ignores the status of these two calls, Modulate.cpp:445-446)
     lArkHeader.EnablePartCipher( lbCryptParts, liNumDevices );
-    return lArkHeader.SaveArk( Slashed( lOutputDirectory ).c_str(), HeaderName().c_str() );
+    return lArkHeader.SaveArk( lOutput.c_str(), HeaderName().c_str() );
 }

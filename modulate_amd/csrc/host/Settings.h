@@ -50,6 +50,18 @@ public:
     inline static bool mbOverwriteOutputFiles = true;
     inline static bool mbIgnoreNewFiles = true;
     inline static bool mbPackAllFiles = false;
+
+    // Addition.  Off (the default) reproduces every deterministic behaviour of the reference, its
+    // quirks included; on (-fixquirks) switches all of these to their corrected forms at once:
+    //   * SaveArk keeps the slice pointer where it was after a part it did not write, so later
+    //     parts get the wrong bytes (CArk.cpp:866, 883-891)      -> fixed: slices follow part sizes
+    //   * ExtractFiles walks every entry whatever its two index arguments say (CArk.cpp:435)
+    //                                                             -> fixed: the range is honoured
+    //   * SaveArk refuses to run unless lpHeaderFilename can be opened in the working directory
+    //     (CArk.cpp:904-909)                                      -> fixed: no such requirement
+    //   * CDtaFile::Save writes top-level trees back to back, which its own Load cannot read when
+    //     there are several (CDtaFile.cpp:371-374)                -> fixed: separators written
+    inline static bool mbFixReferenceQuirks = false;
 };
 
 #define VERBOSE_OUT( out ) do { if( CSettings::mbVerbose ) std::cout << out; } while( 0 )

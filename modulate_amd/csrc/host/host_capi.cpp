@@ -47,6 +47,8 @@ void modhost_set_flags( int overwrite_outputs, int ignore_new_files, int pack_al
     CSettings::mbVerbose = verbose != 0;
 }
 
+void modhost_set_fix_quirks( int on ) { CSettings::mbFixReferenceQuirks = on != 0; }
+
 int modhost_cycle_via_class( uint8_t* buf, uint32_t n, int32_t key, int device )
 {
     return Guard( [ & ] {
@@ -144,5 +146,6 @@ int modhost_ark_file_flags1( const void* ark, int i ) { return A( ark )->GetFile
 int modhost_ark_file_flags2( const void* ark, int i ) { return A( ark )->GetFileFlags2( i ); }
 uint64_t modhost_ark_data_size( const void* ark ) { return A( ark )->GetArkDataSize(); }
 const uint8_t* modhost_ark_data( const void* ark ) { return reinterpret_cast< const uint8_t* >( A( ark )->GetArkData() ); }
+int modhost_ark_data_pinned( const void* ark ) { return A( ark )->IsArkDataPinned() ? 1 : 0; }
 
 } // extern "C"

@@ -13,6 +13,7 @@ extern "C" {
 const char *modhost_last_error(void);
 void modhost_select_platform(int ps4);                                                    /* CSettings::mbPS4 / msPlatform */
 void modhost_set_flags(int overwrite_outputs, int ignore_new_files, int pack_all, int verbose);
+void modhost_set_fix_quirks(int on);                                                      /* CSettings::mbFixReferenceQuirks */
 
 /* CEncryptionCycler().Cycle(buf, n, key) on `device` (-1 = current). 0 ok, -1 threw. */
 int modhost_cycle_via_class(uint8_t *buf, uint32_t n, int32_t key, int device);
@@ -51,6 +52,7 @@ int modhost_ark_file_flags1(const void *ark, int i);
 int modhost_ark_file_flags2(const void *ark, int i);
 uint64_t modhost_ark_data_size(const void *ark);
 const uint8_t *modhost_ark_data(const void *ark);
+int modhost_ark_data_pinned(const void *ark);                                             /* 1: the part buffer is page-locked */
 
 #ifdef __cplusplus
 }

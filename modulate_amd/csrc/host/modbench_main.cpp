@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../../include/modgpu.h"
+#include "../../../include/modgpu_testing.h"
 
 #define TRY( x ) do { int rc_ = ( x ); if( rc_ != MODGPU_OK ) { std::printf( "modgpu error %d: %s\n", rc_, modgpu_last_error() ); return 1; } } while( 0 )
 

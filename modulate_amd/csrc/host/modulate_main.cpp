@@ -1,10 +1,11 @@
 // modulate_main.cpp -- a small Linux command line over the cipher path only:
-//   modulate [-ps3] [-verbose] [-force] [-packall] [-gpus N] [-cryptparts]
+//   modulate [-ps3] [-verbose] [-force] [-packall] [-gpus N] [-cryptparts] [-fixquirks]
 //            -decode <dir> | -unpack <hdr_dir> <out_dir> | -pack <hdr_dir> <in_dir> <out_dir>
 // Flag names and their order-sensitivity follow Modulate/Modulate.cpp:895-972 (flags act when
 // reached).  The song / DTA commands of the reference are out of scope.
-// -gpus and -cryptparts are additions: the second switches on the part-level cipher
-// (BASELINE.json north_star); without it parts are stored raw exactly as the reference does.
+// -gpus, -cryptparts and -fixquirks are additions: -cryptparts switches on the part-level cipher
+// (BASELINE.json north_star; without it parts are stored raw exactly as the reference does),
+// -fixquirks the corrected forms of the reference's deterministic quirks (Settings.h).
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
@@ -23,7 +24,7 @@ int main( int argc, char* argv[] )
     int liNumDevices = 0;
     if( laParams.empty() )
     {
-        std::cout << "usage: modulate [-ps3] [-verbose] [-force] [-packall] [-gpus N] [-cryptparts] -decode <dir> | -unpack <hdr_dir> <out> | -pack <hdr_dir> <in> <out>\n";
+        std::cout << "usage: modulate [-ps3] [-verbose] [-force] [-packall] [-gpus N] [-cryptparts] [-fixquirks] -decode <dir> | -unpack <hdr_dir> <out> | -pack <hdr_dir> <in> <out>\n";
         return 0;
     }
     auto lPop = [ & ]( std::string& lOut ) {
@@ -45,6 +46,7 @@ int main( int argc, char* argv[] )
             else if( !strcasecmp( lCmd.c_str(), "-force" ) ) CSettings::mbOverwriteOutputFiles = true;
             else if( !strcasecmp( lCmd.c_str(), "-packall" ) ) { CSettings::mbPackAllFiles = true; CSettings::mbIgnoreNewFiles = false; }
             else if( !strcasecmp( lCmd.c_str(), "-cryptparts" ) ) lbCryptParts = true;
+            else if( !strcasecmp( lCmd.c_str(), "-fixquirks" ) ) CSettings::mbFixReferenceQuirks = true;
             else if( !strcasecmp( lCmd.c_str(), "-gpus" ) ) leError = lPop( a ) ? ( liNumDevices = std::atoi( a.c_str() ), eError_NoError ) : eError_InvalidParameter;
             else if( !strcasecmp( lCmd.c_str(), "-decode" ) ) leError = lPop( a ) ? Decode( a ) : eError_InvalidParameter;
             else if( !strcasecmp( lCmd.c_str(), "-unpack" ) ) leError = ( lPop( a ) && lPop( b ) ) ? Unpack( a, b, lbCryptParts, liNumDevices ) : eError_InvalidParameter;

@@ -1,0 +1,371 @@
+// host_stream.cpp -- host-buffer and part-file endpoints of the C ABI: how bytes that start in host
+// memory or in a file get through the kernel and back (include/modgpu.h: modgpu_cycle_host,
+// modgpu_cycle_file*, and through them CEncryptionCycler::Cycle and the CArk part cipher).
+//
+// Three routes, picked per call:
+//
+//   pinned, large     the caller's pages are page-locked (modgpu_host_alloc / modgpu_host_register):
+//                     chunk i goes  H2D (DMA straight from the caller's pages) -> kernel in HBM ->
+//                     D2H (DMA straight back), a ring of device slots on their own streams so both
+//                     DMA directions and the kernels overlap.  No host copy, no host threads.
+//                     (Alternative, same bytes: one kernel over PCIe on the pages themselves.)
+//   pageable, large   memcpy -> pinned slot -> H2D -> kernel -> D2H -> pinned slot -> memcpy, spread
+//                     over kPipes independent pipelines (host thread + two slots each): one thread
+//                     copies pageable<->pinned at 22 GB/s, four at 73 (profiles/r01_ubench_hostpath.txt).
+//                     A file endpoint replaces its memcpy by pread / pwrite on the pinned slot.
+//   small (<= 1 MiB)  what the reference's three call sites pass (headers): no DMA submissions at
+//                     all, the kernel reads and writes pinned memory across PCIe itself.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "modgpu_internal.h"
+
+namespace modgpu {
+
+std::atomic<int> g_pinned_mode{0};
+
+namespace {
+
+constexpr int kMaxPipes = 16;
+constexpr int kSlots = 32; // pipes x ring depth: 16 x 2 (staged) or up to 8 x 4 (direct)
+
+// Tunables, read once at load:
+//   MODGPU_HOST_PIPES       host threads / independent pipelines for large pageable buffers (1..16)
+//   MODGPU_HOST_CHUNK_MB    largest slot in MiB (1..256)
+//   MODGPU_HOST_ZEROCOPY_KB largest buffer cycled in place in pinned memory by the kernel (0 = never);
+//                           never larger than a slot, whatever the two variables say
+//   MODGPU_HOST_RING        device slots in flight on the pinned (DMA) route (2..4)
+int env_int(const char *name, int dflt, int lo, int hi)
+{
+    const char *v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    int x = std::atoi(v);
+    return x < lo ? lo : (x > hi ? hi : x);
+}
+const int kPipes = env_int("MODGPU_HOST_PIPES", 4, 1, kMaxPipes);
+const uint64_t kChunk = (uint64_t)env_int("MODGPU_HOST_CHUNK_MB", 16, 1, 256) << 20;
+const uint64_t kZeroCopyMax = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_ZEROCOPY_KB", 1024, 0, 1 << 20) << 10, kChunk);
+const int kRing = env_int("MODGPU_HOST_RING", 4, 2, 4);
+
+struct Staging {
+    std::mutex mu;
+    uint8_t *pinned[kSlots] = {};
+    uint8_t *dev[kSlots] = {};
+    hipStream_t stream[kSlots] = {};
+    uint64_t pinned_cap[kSlots] = {};
+    uint64_t dev_cap[kSlots] = {};
+};
+Staging g_staging[kMaxDevices];
+
+// Slots [first, first + count) get a stream, `need` device bytes and -- if want_pinned -- `need`
+// pinned bytes each (grown on demand, never shrunk).  `need` is clamped to [1 MiB, kChunk].
+int staging_reserve(Staging &s, int first, int count, uint64_t need, bool want_dev, bool want_pinned)
+{
+    need = std::min<uint64_t>(std::max<uint64_t>(need, 1ull << 20), kChunk);
+    for (int i = first; i < first + count; ++i) {
+        if (!s.stream[i]) HIP_TRY(hipStreamCreateWithFlags(&s.stream[i], hipStreamNonBlocking));
+        if (want_pinned && s.pinned_cap[i] < need) {
+            if (s.pinned[i]) HIP_TRY(hipHostFree(s.pinned[i]));
+            s.pinned[i] = nullptr;
+            s.pinned_cap[i] = 0;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.pinned[i]), need, hipHostMallocPortable | hipHostMallocMapped));
+            s.pinned_cap[i] = need;
+        }
+        if (want_dev && s.dev_cap[i] < need) {
+            if (s.dev[i]) HIP_TRY(hipFree(s.dev[i]));
+            s.dev[i] = nullptr;
+            s.dev_cap[i] = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev[i]), need));
+            s.dev_cap[i] = need;
+        }
+    }
+    return MODGPU_OK;
+}
+
+int fill_slot(const Endpoint &src, uint8_t *pinned, uint64_t off, uint64_t len)
+{
+    if (src.mem) {
+        std::memcpy(pinned, src.mem + off, len);
+        return MODGPU_OK;
+    }
+    for (uint64_t done = 0; done < len;) {
+        ssize_t r = ::pread(src.fd, pinned + done, len - done, (off_t)(src.base + off + done));
+        if (r < 0 && errno == EINTR) continue;
+        if (r < 0) return fail_io("pread");
+        if (r == 0) return fail(MODGPU_ERR_IO, "pread: unexpected end of file");
+        done += (uint64_t)r;
+    }
+    return MODGPU_OK;
+}
+
+int drain_slot(const Endpoint &dst, const uint8_t *pinned, uint64_t off, uint64_t len)
+{
+    if (dst.mem) {
+        std::memcpy(dst.mem + off, pinned, len);
+        return MODGPU_OK;
+    }
+    for (uint64_t done = 0; done < len;) {
+        ssize_t r = ::pwrite(dst.fd, pinned + done, len - done, (off_t)(dst.base + off + done));
+        if (r < 0 && errno == EINTR) continue;
+        if (r < 0) return fail_io("pwrite");
+        done += (uint64_t)r;
+    }
+    return MODGPU_OK;
+}
+
+struct Job {
+    const Endpoint &src, &dst;
+    uint64_t n, chunk;
+    int32_t key;
+    uint64_t stream_off;
+    std::atomic<bool> touched{false};
+};
+
+// One pipeline: chunks first, first+stride, ... of the stream through slots [slot0, slot0+ring).
+// A pinned memory endpoint is DMA'd directly; anything else passes through the slot's pinned buffer.
+int run_pipe(Staging &s, int slot0, int ring, Job &j, uint64_t first, uint64_t stride)
+{
+    const uint64_t n_chunks = (j.n + j.chunk - 1) / j.chunk;
+    const bool src_direct = j.src.mem && j.src.pinned, dst_direct = j.dst.mem && j.dst.pinned;
+    auto span = [&](uint64_t c, uint64_t *off, uint64_t *len) {
+        *off = c * j.chunk;
+        *len = std::min<uint64_t>(j.chunk, j.n - *off);
+    };
+    const uint64_t mine = first < n_chunks ? (n_chunks - first + stride - 1) / stride : 0;
+    auto step = [&](uint64_t i) -> int {
+        const int slot = slot0 + (int)(i % (uint64_t)ring);
+        if (i >= (uint64_t)ring) { // retire the chunk that used this slot `ring` trips ago
+            uint64_t off, len;
+            span(first + (i - ring) * stride, &off, &len);
+            HIP_TRY(hipStreamSynchronize(s.stream[slot]));
+            if (!dst_direct) {
+                j.touched.store(true, std::memory_order_relaxed);
+                int rc = drain_slot(j.dst, s.pinned[slot], off, len);
+                if (rc) return rc;
+            }
+        }
+        if (i < mine) {
+            uint64_t off, len;
+            span(first + i * stride, &off, &len);
+            if (src_direct) {
+                HIP_TRY(hipMemcpyAsync(s.dev[slot], j.src.mem + off, len, hipMemcpyHostToDevice, s.stream[slot]));
+            } else {
+                int rc = fill_slot(j.src, s.pinned[slot], off, len);
+                if (rc) return rc;
+                HIP_TRY(hipMemcpyAsync(s.dev[slot], s.pinned[slot], len, hipMemcpyHostToDevice, s.stream[slot]));
+            }
+            int rc = cycle_device_impl(s.dev[slot], len, j.key, j.stream_off + off, s.stream[slot]);
+            if (rc) return rc;
+            if (dst_direct) {
+                j.touched.store(true, std::memory_order_relaxed);
+                HIP_TRY(hipMemcpyAsync(j.dst.mem + off, s.dev[slot], len, hipMemcpyDeviceToHost, s.stream[slot]));
+            } else {
+                HIP_TRY(hipMemcpyAsync(s.pinned[slot], s.dev[slot], len, hipMemcpyDeviceToHost, s.stream[slot]));
+            }
+        }
+        return MODGPU_OK;
+    };
+    int rc = MODGPU_OK;
+    for (uint64_t i = 0; i < mine + (uint64_t)ring && rc == MODGPU_OK; ++i) rc = step(i);
+    if (rc != MODGPU_OK) { // nothing of this call may still be running against the caller's memory once we return
+        const std::string keep = t_err;
+        for (int k = 0; k < ring; ++k) (void)hipStreamSynchronize(s.stream[slot0 + k]);
+        (void)hipGetLastError();
+        t_err = keep;
+    }
+    return rc;
+}
+
+} // namespace
+
+int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t key, uint64_t stream_off, int device,
+                bool *touched)
+{
+    if (touched) *touched = false;
+    if (n == 0) return MODGPU_OK;
+    int dev = 0;
+    int rc = resolve_device(device, &dev);
+    if (rc) return rc;
+    // keys == 0 mod m give the identity: nothing to do in place, a plain copy otherwise
+    const bool identity = (int64_t)key % 0x7FFFFFFFll == 0;
+    const bool in_place = src.mem && src.mem == dst.mem;
+    if (identity && in_place) return MODGPU_OK;
+    if (dev >= kMaxDevices) return fail(MODGPU_ERR_INVALID, "device index beyond staging table");
+    Staging &s = g_staging[dev];
+    std::lock_guard<std::mutex> lock(s.mu);
+
+    const bool src_direct = src.mem && src.pinned, dst_direct = dst.mem && dst.pinned;
+    const bool all_direct = (!src.mem || src_direct) && (!dst.mem || dst_direct);
+    auto account = [&] {
+        g_stats.gpu_calls.fetch_add(1, std::memory_order_relaxed);
+        g_stats.gpu_bytes.fetch_add(n, std::memory_order_relaxed);
+        (all_direct ? g_stats.direct_bytes : g_stats.staged_bytes).fetch_add(n, std::memory_order_relaxed);
+    };
+
+    // ---- kernel over PCIe: header-sized buffers (what the reference's three call sites pass, <= 512 KiB),
+    // and pinned caller memory of any size when that mode is selected.  One launch + one sync; the
+    // kernel reads and writes the pinned pages across PCIe itself (they are device-visible).
+    const int mode = g_pinned_mode.load(std::memory_order_relaxed);
+    if (in_place && src_direct && !identity && (n <= kZeroCopyMax || mode == 2)) {
+        rc = staging_reserve(s, 0, 1, 0, false, false);
+        if (rc) return rc;
+        void *mapped = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&mapped, src.mem, 0));
+        if (touched) *touched = true;
+        rc = cycle_device_impl(mapped, n, key, stream_off, s.stream[0]);
+        hipError_t e = hipStreamSynchronize(s.stream[0]);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail_hip(e, "hipStreamSynchronize (kernel over PCIe)");
+        account();
+        return MODGPU_OK;
+    }
+    if (n <= kZeroCopyMax && src.mem && dst.mem && !identity) {
+        rc = staging_reserve(s, 0, 1, n, false, true);
+        if (rc) return rc;
+        if (s.pinned_cap[0] < n) return fail(MODGPU_ERR_INVALID, "staging slot smaller than the zero-copy buffer");
+        void *mapped = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&mapped, s.pinned[0], 0));
+        std::memcpy(s.pinned[0], src.mem, n);
+        rc = cycle_device_impl(mapped, n, key, stream_off, s.stream[0]);
+        hipError_t e = hipStreamSynchronize(s.stream[0]);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail_hip(e, "hipStreamSynchronize (kernel over PCIe)");
+        if (touched) *touched = true;
+        std::memcpy(dst.mem, s.pinned[0], n);
+        account();
+        return MODGPU_OK;
+    }
+
+    // slot size: the whole buffer if it is small, else ~n/16 between 4 MiB and the cap (measured:
+    // 4 MiB slots are best at 64 MiB, 16 MiB slots from 1 GiB up; profiles/r01_sweep_hostpath.txt)
+    uint64_t chunk = n <= (4ull << 20) ? std::max<uint64_t>(n, 1ull << 20)
+                                       : std::min<uint64_t>(kChunk, std::max<uint64_t>(4ull << 20, ((n >> 4) + 0xFFFFF) & ~0xFFFFFull));
+    chunk = std::min<uint64_t>(chunk, kChunk);
+    const uint64_t n_chunks = (n + chunk - 1) / chunk;
+    Job job{src, dst, n, chunk, key, stream_off};
+    int pipes, ring;
+    if (all_direct && src.mem && dst.mem) { // no host work at all: one thread keeps a ring of slots busy
+        pipes = 1;
+        ring = (int)std::min<uint64_t>((uint64_t)kRing, std::max<uint64_t>(n_chunks, 2));
+    } else {
+        pipes = (int)std::min<uint64_t>((uint64_t)kPipes, (n_chunks + 1) / 2); // a pipeline is worth >= 2 chunks
+        ring = 2;
+    }
+    rc = staging_reserve(s, 0, pipes * ring, chunk, true, !(src_direct && dst_direct));
+    if (rc) return rc;
+
+    if (pipes <= 1) {
+        rc = run_pipe(s, 0, ring, job, 0, 1);
+    } else {
+        std::vector<int> rcs((size_t)pipes, MODGPU_OK);
+        std::vector<std::string> errs((size_t)pipes);
+        std::vector<std::thread> workers;
+        const int phys = physical_of(dev);
+        auto body = [&](int p) {
+            if (hipSetDevice(phys) != hipSuccess) { // HIP's current device is per thread
+                rcs[p] = MODGPU_ERR_HIP;
+                errs[p] = "hipSetDevice in staging worker";
+                return;
+            }
+            rcs[p] = run_pipe(s, p * ring, ring, job, (uint64_t)p, (uint64_t)pipes);
+            if (rcs[p]) errs[p] = t_err;
+        };
+        int started = 1; // pipeline 0 runs on the calling thread
+        try {
+            for (int p = 1; p < pipes; ++p, ++started) workers.emplace_back(body, p);
+        } catch (...) { // thread limit: the pipelines that did not get a thread run here, one after another
+        }
+        body(0);
+        for (int p = started; p < pipes; ++p) body(p);
+        for (auto &w : workers) w.join();
+        for (int p = 0; p < pipes && rc == MODGPU_OK; ++p)
+            if (rcs[p]) {
+                t_err = errs[p];
+                rc = rcs[p];
+            }
+    }
+    if (touched) *touched = job.touched.load();
+    if (rc == MODGPU_OK) account();
+    return rc;
+}
+
+} // namespace modgpu
+
+// ---- file endpoints of the ABI -----------------------------------------------------------------
+using namespace modgpu;
+
+namespace {
+struct Fd { // closes on scope exit
+    int fd = -1;
+    ~Fd() { if (fd >= 0) ::close(fd); }
+};
+} // namespace
+
+extern "C" {
+
+int modgpu_cycle_file(const char *src_path, const char *dst_path, int32_t key, uint64_t stream_off, int device)
+{
+    return guarded([&]() -> int {
+        if (!src_path || !dst_path) return fail(MODGPU_ERR_INVALID, "null path");
+        // dst is opened WITHOUT truncation first: if it turns out to be the source under another
+        // spelling (./a vs a, a symlink, a hard link) truncating it would destroy the input.
+        Fd in, out;
+        in.fd = ::open(src_path, O_RDONLY);
+        if (in.fd < 0) return fail_io(src_path);
+        struct stat st_in, st_out;
+        if (::fstat(in.fd, &st_in) != 0) return fail_io("fstat");
+        out.fd = ::open(dst_path, O_RDWR | O_CREAT, 0644);
+        if (out.fd < 0) return fail_io(dst_path);
+        if (::fstat(out.fd, &st_out) != 0) return fail_io("fstat");
+        const bool in_place = st_in.st_dev == st_out.st_dev && st_in.st_ino == st_out.st_ino;
+        if (!in_place && ::ftruncate(out.fd, 0) != 0) return fail_io("ftruncate");
+        Endpoint src, dst;
+        src.fd = in_place ? out.fd : in.fd;
+        dst.fd = out.fd;
+        return stream_impl(src, dst, (uint64_t)st_in.st_size, key, stream_off, device, nullptr);
+    });
+}
+
+int modgpu_cycle_file_to_host(const char *path, uint64_t file_off, uint8_t *host_dst, uint64_t n, int32_t key,
+                              uint64_t stream_off, int device)
+{
+    return guarded([&]() -> int {
+        if (!path || (n && !host_dst)) return fail(MODGPU_ERR_INVALID, "null path or buffer");
+        Fd in;
+        in.fd = ::open(path, O_RDONLY);
+        if (in.fd < 0) return fail_io(path);
+        Endpoint src, dst;
+        src.fd = in.fd;
+        src.base = file_off;
+        dst.mem = host_dst;
+        dst.pinned = host_range_pinned(host_dst, n);
+        return stream_impl(src, dst, n, key, stream_off, device, nullptr);
+    });
+}
+
+int modgpu_cycle_host_to_file(const uint8_t *host_src, uint64_t n, const char *path, int32_t key, uint64_t stream_off,
+                              int device)
+{
+    return guarded([&]() -> int {
+        if (!path || (n && !host_src)) return fail(MODGPU_ERR_INVALID, "null path or buffer");
+        Fd out;
+        out.fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (out.fd < 0) return fail_io(path);
+        Endpoint src, dst;
+        src.mem = const_cast<uint8_t *>(host_src); // only read from
+        src.pinned = host_range_pinned(host_src, n);
+        dst.fd = out.fd;
+        return stream_impl(src, dst, n, key, stream_off, device, nullptr);
+    });
+}
+
+} // extern "C"

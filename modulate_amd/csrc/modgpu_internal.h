@@ -1,0 +1,86 @@
+// modgpu_internal.h -- shared by the host-side translation units of libmodgpu.so
+// (modgpu_capi.cpp: devices, launch planning, the ABI; host_stream.cpp: host-buffer and file
+// endpoints).  Not installed; the public surface is include/modgpu.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <string>
+
+#include "../../include/modgpu.h"
+
+namespace modgpu {
+
+// ---- errors (text per calling thread) -------------------------------------------------------
+extern thread_local std::string t_err;
+int fail(int code, const char *what);
+int fail(int code, const std::string &what);
+int fail_hip(hipError_t e, const char *where);
+int fail_io(const char *what); // MODGPU_ERR_IO, text = what + strerror(errno)
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return ::modgpu::fail_hip(e_, #expr);                                \
+    } while (0)
+
+// Body of an extern "C" entry point: nothing C++ may leave through the C boundary.
+template <typename F> int guarded(F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(MODGPU_ERR_INVALID, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(MODGPU_ERR_INVALID, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return fail(MODGPU_ERR_INVALID, "internal error");
+    }
+}
+
+// ---- devices ----------------------------------------------------------------------------------
+// `device` arguments of the ABI are LOGICAL indices: normally the HIP ordinal; under
+// MODGPU_DEVICE_ALIAS=N there are N of them and logical d runs on HIP device d mod <visible>.
+constexpr int kMaxDevices = 64;
+int physical_count();
+int logical_count();
+int physical_of(int logical);
+// Makes the device current for the calling thread (HIP's current device is per thread).
+// device < 0 keeps the thread's current device.
+int select_device(int device);
+// Same, and returns the logical index in *out (the current HIP ordinal when device < 0).
+int resolve_device(int device, int *out);
+
+// ---- the launch (device already current) ----------------------------------------------------
+int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off, hipStream_t stream);
+
+// ---- which engine ran -------------------------------------------------------------------------
+struct Stats {
+    std::atomic<uint64_t> gpu_calls{0}, gpu_bytes{0}, gpu_launches{0}, scalar_calls{0}, scalar_bytes{0},
+        staged_bytes{0}, direct_bytes{0}, auto_fallbacks{0};
+};
+extern Stats g_stats;
+bool gpu_required(); // MODGPU_REQUIRE_GPU=1 at load
+
+// ---- page-locked host memory ----------------------------------------------------------------
+// true if [p, p+n) lies inside one allocation of modgpu_host_alloc that is really pinned, or (for
+// large ranges only: the query costs microseconds) inside any other range HIP reports as pinned host memory.
+bool host_range_pinned(const void *p, uint64_t n);
+
+// ---- host-buffer / file endpoints (host_stream.cpp) ---------------------------------------
+// Where a stream's bytes come from / go to: caller memory, or a file read / written at offsets
+// (pread / pwrite: safe from several pipeline threads at once).
+struct Endpoint {
+    uint8_t *mem = nullptr; // if set, bytes live at mem[0..n)
+    int fd = -1;            // else file descriptor, bytes at file offset base + [0..n)
+    uint64_t base = 0;
+    bool pinned = false;    // mem is page-locked and device-visible: DMA'd directly, no staging copy
+};
+// src -> GPU -> dst for n bytes.  *touched (optional) is set once dst may have been modified, so a
+// caller with a second engine knows whether it can still start over.
+int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t key, uint64_t stream_off, int device,
+                bool *touched);
+extern std::atomic<int> g_pinned_mode; // modgpu_debug_set_pinned_mode
+
+} // namespace modgpu

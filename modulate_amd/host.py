@@ -17,6 +17,7 @@ HOOKS = {
     "modhost_last_error": (_cp, []),
     "modhost_select_platform": (None, [_int]),
     "modhost_set_flags": (None, [_int, _int, _int, _int]),
+    "modhost_set_fix_quirks": (None, [_int]),
     "modhost_cycle_via_class": (_int, [_vp, _u32, _i32, _int]),
     "modhost_decode": (_int, [_cp]),
     "modhost_dta_roundtrip": (_int, [_vp, _u64, _vp, _u64, ctypes.POINTER(_u64), _cp, _u64]),
@@ -45,6 +46,7 @@ HOOKS = {
     "modhost_ark_file_flags2": (_int, [_vp, _int]),
     "modhost_ark_data_size": (_u64, [_vp]),
     "modhost_ark_data": (_vp, [_vp]),
+    "modhost_ark_data_pinned": (_int, [_vp]),
 }
 
 
@@ -84,6 +86,11 @@ def select_platform(ps4=True):
 
 def set_flags(overwrite=True, ignore_new=True, pack_all=False, verbose=False):
     lib().modhost_set_flags(int(overwrite), int(ignore_new), int(pack_all), int(verbose))
+
+
+def set_fix_quirks(on):
+    """CSettings::mbFixReferenceQuirks: False (default) = the reference's behaviour, quirks included."""
+    lib().modhost_set_fix_quirks(int(bool(on)))
 
 
 def cycle_via_class(buf, key, device=-1):
@@ -187,6 +194,10 @@ class Ark:
         return [{"name": L.modhost_ark_file_name(self.h, i).decode("latin-1"), "size": L.modhost_ark_file_size(self.h, i),
                  "offset": L.modhost_ark_file_offset(self.h, i), "flags1": L.modhost_ark_file_flags1(self.h, i),
                  "flags2": L.modhost_ark_file_flags2(self.h, i)} for i in range(self.num_files)]
+
+    @property
+    def data_pinned(self):
+        return bool(lib().modhost_ark_data_pinned(self.h))
 
     def data(self):
         n = lib().modhost_ark_data_size(self.h)

@@ -28,11 +28,14 @@ def _write_body(node, out):
             out += struct.pack("<i", c[2])
 
 
-def serialise(top_level):
+def serialise(top_level, separators=True):
+    """separators=True: the form the reference's Load reads (type, 1 between top-level trees,
+    CDtaFile.cpp:95-96).  separators=False: what the reference's Save actually writes -- top-level
+    trees back to back (CDtaFile.cpp:371-374)."""
     out = bytearray(b"\x01" + struct.pack("<i", 1))
     for k, n in enumerate(top_level):
-        if k:
-            out += struct.pack("<ii", n[1], 1)  # what Load expects between top-level nodes (CDtaFile.cpp:95-96)
+        if k and separators:
+            out += struct.pack("<ii", n[1], 1)
         _write_body(n, out)
     return bytes(out)
 

@@ -1,8 +1,11 @@
-"""CPU-only checks of the product library: it loads, exports every symbol include/modgpu.h
-declares, its host-side jump-ahead arithmetic agrees with the oracle, and compute calls fail
-loudly (no CPU fallback) when there is no GPU."""
+"""CPU-only checks of the product library: it loads, exports every symbol its two headers declare,
+its host-side jump-ahead arithmetic agrees with the oracle, the GPU entry points fail loudly when
+there is no GPU, and the library's own host loop (what `CEncryptionCycler::Cycle` falls back to on a
+GPU-less host) reproduces the reference's golden vectors."""
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -10,15 +13,31 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_header_symbols_all_exported(modgpu):
-    src = open(os.path.join(ROOT, "include", "modgpu.h")).read()
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    declared = set(re.findall(r"\b(modgpu_[a-z0-9_]+)\s*\(", src))
-    assert declared == set(modgpu.EXPORTS), declared ^ set(modgpu.EXPORTS)
+    return set(re.findall(r"\b(modgpu_[a-z0-9_]+)\s*\(", src))
+
+
+def test_header_symbols_all_exported(modgpu):
+    assert _declared("modgpu.h") == set(modgpu.EXPORTS), _declared("modgpu.h") ^ set(modgpu.EXPORTS)
+    assert _declared("modgpu_testing.h") == set(modgpu.TESTING_EXPORTS)
     L = modgpu.lib()
-    for name in declared:
+    for name in list(modgpu.EXPORTS) + list(modgpu.TESTING_EXPORTS):
         assert getattr(L, name) is not None
-    assert L.modgpu_abi_version() == 2
+    assert L.modgpu_abi_version() == 3
+    # the library exports nothing else under its prefix (no stray test knobs in the ABI)
+    out = subprocess.run(["nm", "-D", "--defined-only", modgpu.lib_path()], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("modgpu_")}
+    assert exported == set(modgpu.EXPORTS) | set(modgpu.TESTING_EXPORTS), exported ^ (set(modgpu.EXPORTS) | set(modgpu.TESTING_EXPORTS))
+
+
+def test_kernel_source_hash_matches_sources(modgpu):
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("cycle_kernel_impl.h", "cycle_kernel.hip", "cycle_kernel.h", "lcg.h"):
+        h.update(open(os.path.join(ROOT, "modulate_amd", "csrc", f), "rb").read())
+    assert modgpu.kernel_source_hash() == h.hexdigest()
 
 
 def test_state_at_matches_oracle(modgpu, oracle):
@@ -42,8 +61,8 @@ def test_jump_tables(modgpu):
     assert modgpu.jump_table(9) == []
 
 
-def test_no_cpu_fallback(modgpu):
-    """Without a GPU the compute entry points must fail, not quietly compute on the host."""
+def test_gpu_entry_points_fail_loudly_without_gpu(modgpu):
+    """Without a GPU the GPU entry points must fail, not quietly compute on the host."""
     if modgpu.device_count() > 0:
         pytest.skip("GPU present")
     buf = np.arange(64, dtype=np.uint8)
@@ -57,6 +76,11 @@ def test_no_cpu_fallback(modgpu):
         modgpu.hdr_decrypt_host(hdr)
     with pytest.raises(modgpu.ModGpuError):
         modgpu.cycle_parts_host([buf], modgpu.KEY_PS4)
+    with pytest.raises(modgpu.ModGpuError) as e:
+        modgpu.DeviceBuffer(64)
+    assert e.value.code == 2
+    st = modgpu.path_stats()
+    assert st["gpu_calls"] == 0 and st["gpu_launches"] == 0
 
 
 def test_argument_errors(modgpu):
@@ -68,3 +92,106 @@ def test_argument_errors(modgpu):
     with pytest.raises(modgpu.ModGpuError) as e:
         modgpu.hdr_decrypt_host(np.zeros(3, np.uint8))
     assert e.value.code == 1
+
+
+# ---- the library's own host loop (modgpu_cycle_scalar_host / _auto_host) -----------------------
+needs_host_loop = pytest.mark.skipif(os.environ.get("MODGPU_REQUIRE_GPU", "0") not in ("", "0"),
+                                     reason="MODGPU_REQUIRE_GPU forbids the host loop in this process")
+
+
+@needs_host_loop
+def test_host_loop_golden_vectors(modgpu, oracle, golden):
+    """Every fixture the compiled reference produced (tests/golden): keystreams for the 16 keys incl.
+    INT_MIN / -1 / zero-residue, the 34 plaintext cases, the SURVEY 4 KiB vector -- through the product's
+    host loop, on the build box."""
+    for e in golden["keystream"]:
+        ks = modgpu.cycle_scalar_host(np.zeros(1 << 20, np.uint8), e["key"])
+        assert ks[:64].tobytes().hex() == e["first64"], hex(e["key"])
+        assert f"{oracle.fnv1a64(ks):016x}" == e["fnv_1m"]
+    for e in golden["plaintext_cases"]:
+        pt = oracle.splitmix_bytes(e["n"], e["seed"])
+        ct = modgpu.cycle_scalar_host(pt.copy(), e["key"])
+        assert f"{oracle.fnv1a64(ct):016x}" == e["ct_fnv"], e
+        assert ct[:16].tobytes().hex() == e["ct_first16"] and ct[-16:].tobytes().hex() == e["ct_last16"]
+        assert np.array_equal(modgpu.cycle_scalar_host(ct, e["key"]), pt)
+    b = ((np.arange(4096, dtype=np.uint32) * 131 + 7) & 0xFF).astype(np.uint8)
+    ct = modgpu.cycle_scalar_host(b.copy(), golden["survey_4k"]["key"])
+    assert f"{oracle.fnv1a64(ct):016x}" == golden["survey_4k"]["ct_fnv"]
+    # the reference's 2^32-1-byte run: samples around the period wrap and at the very end, by stream offset
+    L = golden["large"]
+    for smp in list(L["samples"]) + [{"off": L["around_period"]["start"], "hex": L["around_period"]["hex"]},
+                                     {"off": L["tail16"]["start"], "hex": L["tail16"]["hex"]}]:
+        m = len(smp["hex"]) // 2
+        assert modgpu.cycle_scalar_host(np.zeros(m, np.uint8), L["key"], stream_off=smp["off"]).tobytes().hex() == smp["hex"]
+
+
+@needs_host_loop
+def test_host_loop_matches_oracle_sizes_offsets_threads(modgpu, oracle):
+    keys = [0x90CFC0AB, 0xC64EED30, 1, 0xFFFFFFFF, 0x80000000, 0, 0x7FFFFFFF, 0x80000001, 12345]
+    offs = [0, 5, 16, oracle.PERIOD - 3, oracle.PERIOD, (1 << 32) - 1, (1 << 40) + 7, (1 << 64) - 70000]
+    for n in (0, 1, 15, 16, 17, 31, 4092, 100_001):
+        for key in keys:
+            for off in offs:
+                pt = oracle.splitmix_bytes(n + 8, n + 1)
+                got = pt.copy()
+                modgpu.cycle_scalar_host(got[3:3 + n], key, off)  # misaligned view, guard bytes either side
+                want = pt.copy()
+                oracle.cycle_at(want[3:3 + n], key, off)
+                assert np.array_equal(got, want), (n, hex(key), off)
+    # >= 4 MiB: contiguous spans on several host threads, each jumping to its own position
+    for n, off in (((4 << 20) + 1, 0), ((33 << 20) + 77, oracle.PERIOD - (5 << 20))):
+        pt = oracle.splitmix_bytes(n, n)
+        want = pt.copy()
+        oracle.cycle_at(want, 0xC64EED30, off)
+        assert np.array_equal(modgpu.cycle_scalar_host(pt.copy(), 0xC64EED30, off), want), n
+
+
+@needs_host_loop
+def test_auto_entry_point_uses_host_loop_without_gpu(modgpu, oracle):
+    """BASELINE config 1 as worded: a 4 KiB blob on the CPU path, no GPU -- through the entry point
+    CEncryptionCycler::Cycle binds to."""
+    if modgpu.device_count() > 0:
+        pytest.skip("GPU present")
+    before = modgpu.path_stats()
+    body = oracle.splitmix_bytes(4092, 0x4D6F64756C617465)
+    got = modgpu.cycle_auto_host(body.copy(), modgpu.KEY_PS4)
+    assert np.array_equal(got, oracle.cycle(body.copy(), oracle.KEY_PS4))
+    after = modgpu.path_stats()
+    assert after["scalar_calls"] == before["scalar_calls"] + 1 and after["auto_fallbacks"] == before["auto_fallbacks"] + 1
+    assert after["scalar_bytes"] == before["scalar_bytes"] + 4092 and after["gpu_calls"] == before["gpu_calls"]
+
+
+def test_require_gpu_forbids_the_host_loop(modgpu):
+    """MODGPU_REQUIRE_GPU=1: no second engine.  (Child process: the switch is read once at load.)"""
+    code = ("import numpy as np, modulate_amd as M\n"
+            "assert M.gpu_required()\n"
+            "b = np.arange(100, dtype=np.uint8); k = b.copy()\n"
+            "for fn, want in ((lambda: M.cycle_scalar_host(b, M.KEY_PS4), (6,)), (lambda: M.cycle_auto_host(b, M.KEY_PS4), (2, 3))):\n"
+            "    try:\n"
+            "        fn(); raise SystemExit('computed on the host')\n"
+            "    except M.ModGpuError as e:\n"
+            "        assert e.code in want, e.code\n"
+            "assert (b == k).all() and M.path_stats()['scalar_calls'] == 0\n"
+            "print('FORBIDDEN_OK')\n")
+    env = dict(os.environ, MODGPU_REQUIRE_GPU="1", HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "FORBIDDEN_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_host_alloc_without_gpu_is_plain_memory(modgpu):
+    if modgpu.device_count() > 0:
+        pytest.skip("GPU present")
+    pb = modgpu.PinnedBuffer(100_000)
+    assert not pb.pinned and pb.ptr % 64 == 0
+    pb.array[:] = 7
+    assert int(pb.array.sum()) == 700_000
+    pb.free()
+    assert modgpu.lib().modgpu_host_free(12345) == 1  # MODGPU_ERR_INVALID: not one of ours
+
+
+def test_device_alias_needs_a_device(modgpu):
+    """MODGPU_DEVICE_ALIAS multiplies real devices; it never conjures one."""
+    env = dict(os.environ, MODGPU_DEVICE_ALIAS="8", HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", "import modulate_amd as M; print('COUNT', M.device_count())"],
+                       capture_output=True, text=True, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "COUNT 0" in r.stdout, r.stdout + r.stderr

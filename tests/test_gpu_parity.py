@@ -1,5 +1,12 @@
 """GPU parity tests: the HIP path, called through the C ABI (include/modgpu.h), against the CPU
-oracle and the committed golden vectors.  Bit-exact is the bar (byte/integer work)."""
+oracle and the committed golden vectors.  Bit-exact is the bar (byte/integer work).
+
+tests/conftest.py sets MODGPU_REQUIRE_GPU=1 before the library is loaded on any machine with a GPU,
+so the library's host loop is unreachable here: a result either came from the gfx950 kernel or the
+call raised.  test_engine_is_the_gpu checks that switch and the per-engine counters."""
+import os
+import subprocess
+import sys
 import threading
 
 import numpy as np
@@ -9,14 +16,37 @@ pytestmark = pytest.mark.gpu
 
 KEYS = [0x90CFC0AB, 0xC64EED30, 1, 0xFFFFFFFF, 0x80000000, 12345, (-127772) & 0xFFFFFFFF, 0xDEADBEEF]
 ZERO_KEYS = [0, 0x7FFFFFFF, 0x80000001]
+HOST_PATH_SIZES = ((16 << 20) - 1, (16 << 20) + 1, (32 << 20) + 1, (100 << 20) + 3, (208 << 20) + 5)
 SIZES = [0, 1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4092, 4095, 4096, 4097,
          8191, 65536 + 3, (1 << 20) - 1, 1 << 20, (1 << 20) + 1]
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
 def gpu(modgpu):
     assert modgpu.device_count() >= 1, "no MI355X visible: the GPU tests cannot run"
+    assert modgpu.gpu_required(), "conftest must have set MODGPU_REQUIRE_GPU=1 before the library was loaded"
     return modgpu
+
+
+def test_engine_is_the_gpu(gpu, oracle):
+    """The host loop is forbidden in this process and the counters move on the GPU side only."""
+    before = gpu.path_stats()
+    pt = oracle.splitmix_bytes(300_000, 77)
+    want = oracle.cycle(pt.copy(), gpu.KEY_PS4)
+    assert np.array_equal(gpu.cycle_host(pt.copy(), gpu.KEY_PS4), want)
+    assert np.array_equal(gpu.cycle_auto_host(pt.copy(), gpu.KEY_PS4), want)  # GPU usable: _auto_ is the GPU too
+    with pytest.raises(gpu.ModGpuError) as e:
+        gpu.cycle_scalar_host(pt.copy(), gpu.KEY_PS4)
+    assert e.value.code == 6  # MODGPU_ERR_FORBIDDEN
+    after = gpu.path_stats()
+    assert after["gpu_calls"] == before["gpu_calls"] + 2 and after["gpu_bytes"] == before["gpu_bytes"] + 600_000
+    assert after["gpu_launches"] >= before["gpu_launches"] + 2
+    assert after["scalar_calls"] == before["scalar_calls"] == 0 and after["auto_fallbacks"] == 0
+    info = gpu.last_launch()
+    assert info["kernel"].startswith("modgpu_cycle_kernel<1, 256,") and info["variant"] == 0 and info["bytes"] == 300_000
 
 
 def test_device_sizes_and_alignments(gpu, oracle):
@@ -109,8 +139,10 @@ def test_split_stream_equals_one_call(gpu, oracle):
 
 
 def test_host_path_chunk_boundaries(gpu, oracle):
-    """Host API across its internal staging chunks (16 MiB), slot rings and 1..6 worker pipelines."""
-    for n in ((16 << 20) - 1, (16 << 20) + 1, (32 << 20) + 1, (100 << 20) + 3, (208 << 20) + 5):
+    """Host API across its internal staging chunks, slot rings and worker pipelines at the default
+    tunables (4 pipelines x 2 slots, slots of n/16 clamped to 4..16 MiB); test_host_path_tunables runs the
+    same sizes off-default."""
+    for n in HOST_PATH_SIZES:
         pt = oracle.splitmix_bytes(n, n)
         ct = gpu.cycle_host(pt.copy(), 0xC64EED30)
         assert np.array_equal(ct, oracle.cycle(pt.copy(), 0xC64EED30)), n
@@ -241,26 +273,24 @@ def test_config2_4gib_part_roundtrip(gpu, oracle, golden):
     dbuf.free()
 
 
-@pytest.mark.parametrize("shape,grid", [("large", 1), ("large", 2), ("large", 3), ("large", 7), ("large", None),
-                                        ("small", 1), ("small", 5), ("small", None)])
-def test_fuzz_forced_shapes(gpu, oracle, shape, grid):
+FUZZ_CASES = [("large", 1), ("large", 2), ("large", 3), ("large", 7), ("large", None), ("small", 1), ("small", 5), ("small", None)]
+
+
+@pytest.mark.parametrize("case", range(len(FUZZ_CASES)))
+def test_fuzz_forced_shapes(gpu, oracle, case):
     """Randomised (size, misalignment, stream offset, key) against the oracle with the launch shape
-    and grid forced, so that the streaming kernel's pipelined loop sees 0, 1, 2, odd and even trip
-    counts, a masked first chunk and ragged last chunks on buffers of a few MiB."""
-    import os
-    rng = np.random.default_rng(hash((shape, grid)) & 0xFFFF)
-    old = {k: os.environ.get(k) for k in ("MODGPU_FORCE_SHAPE", "MODGPU_GRID")}
-    os.environ["MODGPU_FORCE_SHAPE"] = shape
-    if grid is None:
-        os.environ.pop("MODGPU_GRID", None)
-    else:
-        os.environ["MODGPU_GRID"] = str(grid)
+    and grid forced (modgpu_debug_set_launch), so that the streaming kernel's pipelined loop sees 0, 1,
+    2, odd and even trip counts, a masked first chunk and ragged last chunks on buffers of a few MiB.
+    Fixed seeds: the same cases every run."""
+    shape, grid = FUZZ_CASES[case]
+    rng = np.random.default_rng(20260000 + case)
+    gpu.debug_set_launch(shape, grid or 0)
     try:
         cap = (6 << 20) + 4096
         dbuf = gpu.DeviceBuffer(cap)
         chunk = 131072 if shape == "large" else 4096
         sizes = [0, 1, 15, 16, 17, chunk - 16, chunk, chunk + 16, 2 * chunk, 2 * chunk + 5, 3 * chunk - 1, 5 * chunk + 123]
-        sizes += [int(x) for x in rng.integers(0, 6 << 20, size=int(os.environ.get("MODGPU_FUZZ_CASES", "14")))]
+        sizes += [int(x) for x in rng.integers(0, 6 << 20, size=14)]
         for n in sizes:
             base = int(rng.integers(0, 4096)) if n % 3 else int(rng.integers(0, 300000))
             base = min(base, cap - n - 64)
@@ -271,17 +301,17 @@ def test_fuzz_forced_shapes(gpu, oracle, shape, grid):
             dbuf.upload(whole, offset=lo)
             dbuf.cycle(key, n=n, offset=base, stream_off=so)
             dbuf.sync()
+            if n >= 16 and oracle.as_int32(key) % 0x7FFFFFFF:
+                info = gpu.last_launch()
+                assert info["variant"] == (1 if shape == "large" else 0) and info["chunk_bytes"] == chunk
+                assert grid is None or info["grid"] <= grid
             got = dbuf.download(n + 128, offset=lo)
             want = whole.copy()
             oracle.cycle_at(want[base - lo:base - lo + n], key, so)
             assert np.array_equal(got, want), (shape, grid, n, base, hex(key), so)
         dbuf.free()
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        gpu.debug_set_launch(None, 0)
 
 
 def test_part_files_streamed_through_gpu(gpu, oracle, tmp_path):
@@ -329,3 +359,181 @@ def test_host_api_beyond_4gib(gpu, oracle):
     P = oracle.PERIOD
     assert np.array_equal(buf[:1 << 26], buf[P:P + (1 << 26)])
     assert np.array_equal(buf[P:2 * P - (1 << 20)][-(1 << 24):], buf[0:P - (1 << 20)][-(1 << 24):])
+
+
+# ---- host-path tunables off-default (read once at library load: one child process per setting) ----------
+_TUNABLE_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import modulate_amd as M
+from oracle import oracle as O
+assert M.gpu_required() and M.device_count() >= 1
+sizes = %r
+for n in sizes:
+    pt = O.splitmix_bytes(n, n)
+    want = O.cycle(pt.copy(), 0xC64EED30)
+    ct = M.cycle_host(pt.copy(), 0xC64EED30)
+    assert np.array_equal(ct, want), n
+    assert np.array_equal(M.cycle_host(ct, 0xC64EED30), pt), n
+    pb = M.PinnedBuffer(n + 64)                      # the same through page-locked caller memory, misaligned
+    for mode in (1, 2):
+        M.debug_set_pinned_mode(mode)
+        pb.array[:] = 0xEE
+        pb.array[7:7 + n] = pt
+        M.cycle_host(pb.array[7:7 + n], 0xC64EED30)
+        assert np.array_equal(pb.array[7:7 + n], want), (n, mode)
+        assert (pb.array[:7] == 0xEE).all() and (pb.array[7 + n:] == 0xEE).all()
+    M.debug_set_pinned_mode(0)
+    pb.free()
+st = M.path_stats()
+assert st["scalar_calls"] == 0 and st["gpu_calls"] == 4 * len(sizes), st
+print("TUNABLES_OK", st["staged_bytes"], st["direct_bytes"])
+"""
+
+TUNABLES = [{"MODGPU_HOST_PIPES": "1"}, {"MODGPU_HOST_PIPES": "2"}, {"MODGPU_HOST_PIPES": "8"}, {"MODGPU_HOST_PIPES": "16"},
+            {"MODGPU_HOST_CHUNK_MB": "1"}, {"MODGPU_HOST_CHUNK_MB": "4"}, {"MODGPU_HOST_CHUNK_MB": "64"},
+            {"MODGPU_HOST_ZEROCOPY_KB": "0"}, {"MODGPU_HOST_RING": "2"},
+            # ADVICE r1: a zero-copy limit above the slot size used to overrun the pinned staging buffer
+            {"MODGPU_HOST_CHUNK_MB": "1", "MODGPU_HOST_ZEROCOPY_KB": "2048"},
+            {"MODGPU_HOST_PIPES": "16", "MODGPU_HOST_CHUNK_MB": "1"}]
+
+
+@pytest.mark.parametrize("env", TUNABLES, ids=lambda e: ",".join(f"{k[12:]}={v}" for k, v in e.items()))
+def test_host_path_tunables(gpu, env):
+    """MODGPU_HOST_PIPES / _CHUNK_MB / _ZEROCOPY_KB / _RING off their defaults, on the chunk-boundary sizes,
+    pageable and pinned caller memory, encrypt + decrypt, whole-buffer compare against the oracle."""
+    sizes = [4097, (1 << 20) + 1, (2 << 20) - 1] + list(HOST_PATH_SIZES[:4])
+    if env.get("MODGPU_HOST_CHUNK_MB") == "64" or env.get("MODGPU_HOST_PIPES") in ("8", "16"):
+        sizes.append(HOST_PATH_SIZES[4])
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-c", _TUNABLE_CHILD % (ROOT, sizes)], capture_output=True, text=True, env=e, timeout=900)
+    assert r.returncode == 0 and "TUNABLES_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---- page-locked caller memory (modgpu_host_alloc): no staging copy --------------------------------------
+@pytest.mark.parametrize("mode", [1, 2], ids=["dma", "kernel_over_pcie"])
+def test_pinned_host_buffers(gpu, oracle, mode):
+    """modgpu_cycle_host on ranges inside a modgpu_host_alloc allocation: DMA'd (or read by the kernel)
+    straight from / to the caller's pages.  Sizes across the slot boundaries, misaligned starts, stream
+    offsets, guard bytes either side, and the counters say no byte was staged."""
+    gpu.debug_set_pinned_mode(mode)
+    try:
+        cap = (208 << 20) + 4096
+        pb = gpu.PinnedBuffer(cap)
+        assert pb.pinned
+        for n, base, so in ((0, 0, 0), (1, 5, 0), (4092, 4, 0), (1 << 20, 0, 7), ((1 << 20) + 1, 3, 0), ((4 << 20) + 5, 13, 1 << 33),
+                            ((16 << 20) - 1, 1, 0), ((16 << 20) + 1, 0, oracle.PERIOD - 5), ((100 << 20) + 3, 9, 0), ((208 << 20) + 5, 64, 12345)):
+            pt = oracle.splitmix_bytes(n, n + 1)
+            pb.array[:base + n + 64] = 0xA5
+            pb.array[base:base + n] = pt
+            before = gpu.path_stats()
+            gpu.cycle_host(pb.array[base:base + n], 0x90CFC0AB, stream_off=so)
+            after = gpu.path_stats()
+            want = pt.copy()
+            oracle.cycle_at(want, 0x90CFC0AB, so)
+            assert np.array_equal(pb.array[base:base + n], want), (n, base, so)
+            assert (pb.array[:base] == 0xA5).all() and (pb.array[base + n:base + n + 64] == 0xA5).all()
+            assert after["staged_bytes"] == before["staged_bytes"] and after["direct_bytes"] == before["direct_bytes"] + n
+        # a range that pokes out of the allocation is not "pinned": it takes the staged route and is still right
+        assert not gpu.lib().modgpu_host_is_pinned(pb.ptr + cap - 10, 11)
+        pb.free()
+    finally:
+        gpu.debug_set_pinned_mode(0)
+
+
+def test_pinned_endpoints_of_file_streams(gpu, oracle, tmp_path):
+    """CArk's part buffer is page-locked: file -> GPU -> pinned memory and pinned memory -> GPU -> file skip
+    the memory-side copy (what LoadArkData / SaveArk do with the part cipher on, CArk.cpp:751, 883)."""
+    n = (37 << 20) + 11
+    pt = oracle.splitmix_bytes(n, 3)
+    want = oracle.cycle(pt.copy(), oracle.KEY_PS4)
+    pb = gpu.PinnedBuffer(n + 32)
+    src = tmp_path / "p.ark"
+    pt.tofile(src)
+    before = gpu.path_stats()
+    gpu.cycle_file_to_host(src, n, gpu.KEY_PS4, out=pb.array[16:16 + n])
+    assert np.array_equal(pb.array[16:16 + n], want)
+    gpu.cycle_host_to_file(pb.array[16:16 + n], tmp_path / "back.ark", gpu.KEY_PS4)
+    assert np.array_equal(np.fromfile(tmp_path / "back.ark", dtype=np.uint8), pt)
+    assert np.array_equal(pb.array[16:16 + n], want)  # the source is not modified
+    after = gpu.path_stats()
+    assert after["direct_bytes"] == before["direct_bytes"] + 2 * n and after["staged_bytes"] == before["staged_bytes"]
+    pb.free()
+
+
+def test_cycle_file_same_file_by_another_name(gpu, oracle, tmp_path):
+    """src and dst naming one file through different spellings / a symlink / a hard link must be
+    treated as in place (dst used to be truncated first, destroying the part)."""
+    n = (3 << 20) + 7
+    pt = oracle.splitmix_bytes(n, 9)
+    want = oracle.cycle(pt.copy(), oracle.KEY_PS3)
+    for how in ("dot", "symlink", "hardlink"):
+        d = tmp_path / how
+        d.mkdir()
+        f = d / "part.ark"
+        pt.tofile(f)
+        if how == "dot":
+            other = d / "." / "sub" / ".." / "part.ark"
+            (d / "sub").mkdir()
+        elif how == "symlink":
+            other = d / "alias.ark"
+            os.symlink(f, other)
+        else:
+            other = d / "link.ark"
+            os.link(f, other)
+        gpu.cycle_file(f, other, gpu.KEY_PS3)
+        assert np.array_equal(np.fromfile(f, dtype=np.uint8), want), how
+
+
+# ---- N workers on one GPU: MODGPU_DEVICE_ALIAS (read at load: child process) ---------------------------
+_ALIAS_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import modulate_amd as M
+from oracle import oracle as O
+assert M.gpu_required() and M.device_count() == 8, M.device_count()
+# BASELINE config 3's shape -- 8 parts, part i on (logical) GPU i -- at sizes this box's RAM holds:
+# modgpu_cycle_parts_host runs 8 worker threads, each with its own staging context and streams.
+sizes = [(192 << 20) + 17 * i for i in range(8)]
+parts = [O.splitmix_bytes(s, 0x4D6F64756C617465 + i) for i, s in enumerate(sizes)]
+keep = [p.copy() for p in parts]
+M.cycle_parts_host(parts, M.KEY_PS4, 8)
+for i, (p, k) in enumerate(zip(parts, keep)):
+    assert np.array_equal(p, O.cycle(k.copy(), O.KEY_PS4)), i      # each part its own Cycle from offset 0
+M.cycle_parts_host(parts, M.KEY_PS4, 0)                            # decrypt pass, "all devices"
+for p, k in zip(parts, keep):
+    assert np.array_equal(p, k)
+# more parts than devices, ragged sizes, some empty; and fewer devices than the alias offers
+sizes = [0, 1, 4096, 1_000_003, (8 << 20) + 5, 77, (33 << 20) + 1, 0, 5_000_000, 16, (17 << 20) - 3]
+for n_dev in (8, 3):
+    parts = [O.splitmix_bytes(s, 100 + i) for i, s in enumerate(sizes)]
+    want = [O.cycle(p.copy(), O.KEY_PS3) for p in parts]
+    M.cycle_parts_host(parts, M.KEY_PS3, n_dev)
+    for g, w in zip(parts, want):
+        assert np.array_equal(g, w)
+# every logical device is usable through the per-call device argument, device-resident and host paths
+pt = O.splitmix_bytes((5 << 20) + 3, 5)
+want = O.cycle(pt.copy(), O.KEY_PS4)
+for d in range(8):
+    assert np.array_equal(M.cycle_host(pt.copy(), M.KEY_PS4, device=d), want), d
+    b = M.DeviceBuffer(pt.size, device=d); b.upload(pt); b.cycle(M.KEY_PS4); b.sync()
+    assert np.array_equal(b.download(), want), d
+    b.free()
+try:
+    M.cycle_host(pt.copy(), M.KEY_PS4, device=8)
+    raise SystemExit("device 8 of 8 accepted")
+except M.ModGpuError as e:
+    assert e.code == 1
+st = M.path_stats()
+assert st["scalar_calls"] == 0, st
+print("ALIAS_OK", st["gpu_calls"], st["gpu_bytes"])
+"""
+
+
+def test_eight_workers_on_aliased_devices(gpu):
+    """the N-worker sharding code (modgpu_cycle_parts_host, per-device staging contexts)
+    executed with 8 workers: 8 logical devices aliased onto this box's GPU.  Parts are independent streams
+    (CArk.cpp:741-755, 849-897): results must equal the oracle's per-part Cycle whatever the worker count."""
+    e = dict(os.environ, MODGPU_DEVICE_ALIAS="8")
+    r = subprocess.run([sys.executable, "-c", _ALIAS_CHILD % ROOT], capture_output=True, text=True, env=e, timeout=1200)
+    assert r.returncode == 0 and "ALIAS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,8 +1,12 @@
 """CPU-only checks of the C++ host mirror (libmodulate_host.so): it loads, the CArk header writer
 and part-split bookkeeping agree with the independent Python restatement (oracle/ark_header.py;
-parity unpinned -- the reference has no fixtures for this format), and anything that needs the
-cipher fails loudly without a GPU instead of computing on the host."""
+parity unpinned -- the reference has no fixtures for this format), CEncryptionCycler::Cycle keeps
+the reference's "cannot fail" contract on a GPU-less host (BASELINE config 1) unless
+MODGPU_REQUIRE_GPU forbids it, and the reference's deterministic quirks are the default with their
+fixes behind one switch."""
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -15,7 +19,14 @@ def host():
     from modulate_amd import host as H
     H.lib()
     H.set_flags(overwrite=True, ignore_new=True, pack_all=False, verbose=False)
+    H.set_fix_quirks(False)
     return H
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "modulate_amd", "bin", "modulate")
+needs_host_loop = pytest.mark.skipif(os.environ.get("MODGPU_REQUIRE_GPU", "0") not in ("", "0"),
+                                     reason="MODGPU_REQUIRE_GPU forbids the host loop in this process")
 
 
 def synth_table(n, seed=1):
@@ -96,21 +107,188 @@ def test_bad_arguments(host):
     a.close()
 
 
-def test_cipher_needs_gpu(host, modgpu):
-    """No CPU fallback behind the C++ seam: Cycle throws when the HIP path is unavailable."""
+@needs_host_loop
+def test_config1_cycle_cannot_fail_without_gpu(host, modgpu, oracle, tmp_path):
+    """BASELINE config 1 as worded ("single 4 KiB .dta decrypt on reference CPU path, no GPU"): the
+    reference's Cycle returns void and cannot fail (CEncryptionCycler.cpp:4-14), so on a GPU-less host
+    the class, the three framed call sites and `modulate -decode` all work, bit-exact."""
     if modgpu.device_count() > 0:
         pytest.skip("GPU present")
-    buf = np.arange(100, dtype=np.uint8)
-    keep = buf.copy()
-    with pytest.raises(host.HostError) as e:
-        host.cycle_via_class(buf, 0x90CFC0AB)
-    assert e.value.code == -1 and "GPU path failed" in str(e.value) and np.array_equal(buf, keep)
+    from oracle import dta_tree as DT
+    before = modgpu.path_stats()
+    for key in (0x90CFC0AB, 0xC64EED30, 1, 0xFFFFFFFF, 0x80000000, 0, 0x7FFFFFFF):
+        for n in (0, 1, 15, 4092, 100_001):
+            whole = oracle.splitmix_bytes(n + 4, n + 1)
+            got = whole.copy()
+            host.cycle_via_class(got[4:], key)  # CEncryptionCycler().Cycle(buf+4, size-4, key)
+            want = whole.copy()
+            oracle.cycle(want[4:], key)
+            assert np.array_equal(got, want), (hex(key), n)
+    after = modgpu.path_stats()
+    if not os.environ.get("MODULATE_HOST_LIB"):  # (the sanitizer build binds to a stub, not to the library that counts)
+        assert after["auto_fallbacks"] > before["auto_fallbacks"] and after["gpu_launches"] == 0
+    # a 4 KiB DTA blob framed like a header, on disk as main_ps4.hdr: -decode writes magic + plaintext
+    tree = DT.synth_tree(np.random.default_rng(4096), target_bytes=4092)
+    body = np.frombuffer(DT.serialise(tree), dtype=np.uint8)
+    for ps4, plat in ((True, "ps4"), (False, "ps3")):
+        framed = np.concatenate([np.zeros(4, np.uint8), body])
+        assert oracle.hdr_encrypt(framed, ps4) == 0
+        d = tmp_path / plat
+        d.mkdir()
+        framed.tofile(d / f"main_{plat}.hdr")
+        r = subprocess.run([EXE] + ([] if ps4 else ["-ps3"]) + ["-decode", str(d)], capture_output=True, text=True)
+        assert r.returncode == 0 and "Complete!" in r.stdout, r.stdout + r.stderr
+        dec = np.fromfile(d / f"main_{plat}.hdr.dec", dtype=np.uint8)
+        assert np.array_equal(dec[4:], body) and np.array_equal(dec[:4], framed[:4])
+        out, dump = host.dta_roundtrip(dec[4:].tobytes())
+        assert out == body.tobytes() and dump == DT.dump(tree)
+
+
+@needs_host_loop
+def test_header_save_load_framing_without_gpu(host, modgpu, oracle, header_cwd, tmp_path):
+    """SaveArk / Load framing (CArk.cpp:914-915, 1135-1136, 328-339) on a GPU-less host: header on disk ==
+    oracle ciphertext of the plain image; Load decrypts it back; parts are raw slices."""
+    if modgpu.device_count() > 0:
+        pytest.skip("GPU present")
+    for ps4 in (True, False):
+        host.select_platform(ps4)
+        plat = "ps4" if ps4 else "ps3"
+        names, sizes = synth_table(300, seed=8)
+        data = np.random.default_rng(8).integers(0, 256, size=sum(sizes), dtype=np.uint8)
+        a = host.Ark()
+        a.construct_from_table(names, sizes, 3, f"main_{plat}")
+        a.build_from_memory(data)
+        assert not a.data_pinned
+        out = str(tmp_path / plat) + "/"
+        os.makedirs(out)
+        a.save(out, f"main_{plat}.hdr")
+        plain = a.serialise_header(encrypt=False)
+        want = plain.copy()
+        assert oracle.hdr_encrypt(want, ps4) == 0
+        assert np.array_equal(np.fromfile(out + f"main_{plat}.hdr", dtype=np.uint8), want)
+        b = host.Ark().load(out + f"main_{plat}.hdr")
+        assert b.ark_sizes() == a.ark_sizes() and [f["name"] for f in b.files()] == [f["name"] for f in AH.parse(plain.tobytes())["files"]]
+        b.load_data()
+        assert np.array_equal(b.data(), data)
+        a.close(), b.close()
+    host.select_platform(True)
+
+
+def test_require_gpu_makes_cycle_throw_without_gpu(host):
+    """The opt-in strict mode: MODGPU_REQUIRE_GPU=1 and no GPU -> Cycle throws, buffer untouched."""
+    code = ("import numpy as np\n"
+            "from modulate_amd import host as H\n"
+            "b = np.arange(100, dtype=np.uint8); k = b.copy()\n"
+            "try:\n"
+            "    H.cycle_via_class(b, 0x90CFC0AB); raise SystemExit('computed')\n"
+            "except H.HostError as e:\n"
+            "    assert e.code == -1 and 'GPU path failed' in str(e), str(e)\n"
+            "assert (b == k).all()\n"
+            "print('THROWS_OK')\n")
+    env = dict(os.environ, MODGPU_REQUIRE_GPU="1", HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "THROWS_OK" in r.stdout, r.stdout + r.stderr
+
+
+# ---- the reference's deterministic quirks are the default; -fixquirks / mbFixReferenceQuirks corrects them
+def _small_ark(host, n_arks=3, n=60, seed=21):
+    names, sizes = synth_table(n, seed=seed)
+    data = np.random.default_rng(seed).integers(0, 256, size=sum(sizes), dtype=np.uint8)
     a = host.Ark()
-    a.construct_from_table(["x"], [4], 1)
-    a.build_from_memory(np.zeros(4, np.uint8))
-    with pytest.raises(host.HostError):
-        a.serialise_header(encrypt=True)
+    a.construct_from_table(names, sizes, n_arks, "main_ps4")
+    a.build_from_memory(data)
+    return a, names, sizes, data
+
+
+@needs_host_loop
+def test_quirk_savearc_needs_header_in_cwd(host, tmp_path, monkeypatch):
+    """CArk.cpp:904-909: SaveArk opens lpHeaderFilename (bare name, working directory) before anything else."""
+    host.select_platform(True)
+    a, *_ = _small_ark(host)
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    monkeypatch.chdir(empty)
+    out = str(tmp_path / "out") + "/"
+    os.makedirs(out)
+    with pytest.raises(host.HostError) as e:
+        a.save(out, "main_ps4.hdr")
+    assert e.value.code == 1 and not os.path.exists(out + "main_ps4.hdr")  # eError_FailedToOpenFile, nothing written
+    host.set_fix_quirks(True)
+    try:
+        a.save(out, "main_ps4.hdr")
+        assert os.path.getsize(out + "main_ps4.hdr") > 0
+    finally:
+        host.set_fix_quirks(False)
+    (empty / "main_ps4.hdr").write_bytes(b"x")
+    a.save(out, "main_ps4.hdr")  # reference mode, header present: fine
     a.close()
+
+
+@needs_host_loop
+def test_quirk_skipped_part_keeps_slice_pointer(host, header_cwd, tmp_path):
+    """CArk.cpp:853-869, 883-891: with overwriting off, an existing non-empty part is skipped and lpArkPtr is
+    NOT advanced, so every later part is written from the slice of the part before it."""
+    host.select_platform(True)
+    a, names, sizes, data = _small_ark(host, n_arks=4)
+    parts, paths = a.ark_sizes(), a.ark_paths()
+    bounds = np.cumsum([0] + parts)
+    for fix in (False, True):
+        out = str(tmp_path / f"fix{int(fix)}") + "/"
+        os.makedirs(out)
+        with open(out + paths[1], "wb") as f:
+            f.write(b"keep me")
+        host.set_flags(overwrite=False, ignore_new=True, pack_all=False, verbose=False)
+        host.set_fix_quirks(fix)
+        try:
+            a.save(out, "main_ps4.hdr")
+        finally:
+            host.set_flags(overwrite=True, ignore_new=True, pack_all=False, verbose=False)
+            host.set_fix_quirks(False)
+        assert open(out + paths[1], "rb").read() == b"keep me"
+        assert np.array_equal(np.fromfile(out + paths[0], dtype=np.uint8), data[bounds[0]:bounds[1]])
+        for i in (2, 3):
+            start = bounds[i] if fix else bounds[i] - parts[1]  # reference: one part's worth behind
+            assert np.array_equal(np.fromfile(out + paths[i], dtype=np.uint8), data[start:start + parts[i]]), (fix, i)
+    a.close()
+
+
+@needs_host_loop
+def test_quirk_extract_ignores_range(host, header_cwd, tmp_path):
+    """CArk.cpp:435: ExtractFiles walks all miNumFiles entries whatever (first, count) it was given."""
+    host.select_platform(True)
+    a, names, sizes, data = _small_ark(host)
+    out = str(tmp_path / "packed") + "/"
+    os.makedirs(out)
+    a.save(out, "main_ps4.hdr")
+    for fix in (False, True):
+        b = host.Ark().load(out + "main_ps4.hdr")
+        target = str(tmp_path / f"x{int(fix)}") + "/"
+        host.set_fix_quirks(fix)
+        try:
+            b.extract(target, first=5, count=7)
+        finally:
+            host.set_fix_quirks(False)
+        written = sorted(os.path.relpath(os.path.join(r, f), target) for r, _, fs in os.walk(target) for f in fs)
+        listed = [f["name"] for f in b.files()]
+        assert written == (sorted(listed[5:12]) if fix else sorted(listed))
+        b.close()
+    a.close()
+
+
+def test_quirk_dta_top_level_trees_back_to_back(host):
+    """CDtaFile.cpp:371-374: Save writes the root's children back to back, no type/1 separator between
+    them -- so several top-level trees do not survive the reference's own Load.  Default here too."""
+    from oracle import dta_tree as DT
+    multi = [("tree", 16, 1, [("int", 0, 5)]), ("tree", 17, 9, [("int", 0, 6)]), ("tree", 16, 3, [("str", 5, "x")])]
+    blob = DT.serialise(multi)  # the loadable form: separators present
+    out, _ = host.dta_roundtrip(blob)
+    assert out == DT.serialise(multi, separators=False) and out != blob
+    host.set_fix_quirks(True)
+    try:
+        out2, dump2 = host.dta_roundtrip(blob)
+        assert out2 == blob and dump2 == DT.dump(multi)
+    finally:
+        host.set_fix_quirks(False)
 
 
 def test_cli_usage_and_unknown_flag():
@@ -135,10 +313,14 @@ def test_dta_roundtrip_matches_restatement(host):
     out, dump = host.dta_roundtrip(blob)
     assert out == blob                      # C++ writer == Python writer on the C++ parse of the Python image
     assert dump == DT.dump(tree)            # node for node
-    # several top-level trees (the reference's Save cannot round-trip these; ours writes the separators Load expects)
+    # several top-level trees round-trip only with the quirk fix on (see test_quirk_dta_top_level_trees_back_to_back)
     multi = [tree[0], ("tree", 17, 9, [("int", 0, 5)]), ("tree", 16, 3, [("str", 5, "x"), ("float", 1, 0x40490FDB)])]
     blob2 = DT.serialise(multi)
-    out2, dump2 = host.dta_roundtrip(blob2)
+    host.set_fix_quirks(True)
+    try:
+        out2, dump2 = host.dta_roundtrip(blob2)
+    finally:
+        host.set_fix_quirks(False)
     assert out2 == blob2 and dump2 == DT.dump(multi)
 
 

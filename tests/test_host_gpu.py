@@ -21,6 +21,7 @@ def host(modgpu):
     from modulate_amd import host as H
     H.lib()
     H.set_flags(overwrite=True, ignore_new=True, pack_all=False, verbose=False)
+    H.set_fix_quirks(False)  # the reference's behaviour, quirks included (SaveArk wants the header in the cwd: header_cwd)
     H.select_platform(True)
     return H
 
@@ -46,7 +47,7 @@ def test_cycle_via_reference_class_signature(host, oracle):
 
 
 @pytest.mark.parametrize("ps4", [True, False])
-def test_save_load_roundtrip_and_framing(host, oracle, tmp_path, ps4):
+def test_save_load_roundtrip_and_framing(host, oracle, tmp_path, header_cwd, ps4):
     host.select_platform(ps4)
     plat = "ps4" if ps4 else "ps3"
     names, sizes, data = synth(700, 3)
@@ -85,7 +86,7 @@ def test_save_load_roundtrip_and_framing(host, oracle, tmp_path, ps4):
     a.close(), b.close()
 
 
-def test_config5_roundtrip_unpack_repack(host, oracle, tmp_path):
+def test_config5_roundtrip_unpack_repack(host, oracle, tmp_path, header_cwd):
     """decrypt -> unpack -> repack -> encrypt; output bytes identical to the first pack."""
     host.select_platform(True)
     names, sizes, data = synth(400, 9)
@@ -125,7 +126,7 @@ def test_config5_roundtrip_unpack_repack(host, oracle, tmp_path):
     a.close(), b.close()
 
 
-def test_config4_pack_with_part_cipher(host, oracle, tmp_path):
+def test_config4_pack_with_part_cipher(host, oracle, modgpu, tmp_path, header_cwd):
     """Config 4 at test scale: synthetic table -> multi-part .ark + encrypted header, parts cycled
     on the GPU (north_star); every part == oracle Cycle of its raw slice from stream offset 0."""
     host.select_platform(True)
@@ -134,9 +135,13 @@ def test_config4_pack_with_part_cipher(host, oracle, tmp_path):
     a.construct_from_table(names, sizes, 5, "main_ps4")
     a.build_from_memory(data)
     a.enable_part_cipher(True, 1)
+    assert a.data_pinned  # the part buffer is page-locked (modgpu_host_alloc): slices are DMA'd from where they lie
     out = str(tmp_path) + "/"
+    before = modgpu.path_stats()
     a.save(out, "main_ps4.hdr")
-    assert np.array_equal(a.data(), data)  # SaveArk restores the in-memory slices
+    after = modgpu.path_stats()
+    assert after["direct_bytes"] - before["direct_bytes"] == data.size  # every part byte went without a staging copy
+    assert np.array_equal(a.data(), data)  # SaveArk leaves the in-memory slices as they were
     off = 0
     for path, size in zip(a.ark_paths(), a.ark_sizes()):
         want = oracle.cycle(data[off:off + size].copy(), oracle.KEY_PS4)
@@ -215,3 +220,107 @@ def test_max_length_one_cycle_call_matches_reference_digest(host, oracle, golden
     host.cycle_via_class(buf, L["key"])
     assert f"{oracle.fnv1a64(buf):016x}" == L["fnv_all"]
     assert buf[L["tail16"]["start"]:].tobytes().hex() == L["tail16"]["hex"]
+
+
+def synth_100k():
+    """100 000 entries, names dir{k%97}/sub{k%13}/f{k}.bin, sizes uniform in [0, 64 KiB]."""
+    rng = np.random.default_rng(0x4D6F6475)
+    n = 100_000
+    names = [f"dir{k % 97}/sub{k % 13}/f{k}.bin" for k in range(n)]
+    sizes = [int(x) for x in rng.integers(0, 65537, size=n)]
+    total = sum(sizes)
+    tile = rng.integers(0, 256, size=64 << 20, dtype=np.uint8)
+    data = np.resize(tile, total)
+    data[::4099] ^= np.arange(len(data[::4099]), dtype=np.uint64).astype(np.uint8)  # no exact 64 MiB period
+    return names, sizes, data
+
+
+def test_config4_full_size_100k_entries(host, oracle, modgpu, tmp_path, header_cwd):
+    """BASELINE config 4 at its stated size: 100 000 synthetic entries (3.3 GB) -> 8-part .ark + encrypted
+    header on one GPU.  The 4.9 MB header takes the multi-slot host path (not the <= 1 MiB kernel-over-PCIe
+    one) and must equal the independent Python restatement, encrypted by the oracle; every ~411 MB part must
+    equal the oracle's Cycle of its raw slice; reading back through LoadArkData restores the input."""
+    host.select_platform(True)
+    names, sizes, data = synth_100k()
+    a = host.Ark()
+    a.construct_from_table(names, sizes, 8, "main_ps4")
+    a.build_from_memory(data)
+    assert a.num_files == 100_000 and a.data_pinned
+    offs, parts = AH.split_into_arks(sizes, AH.even_plan(sum(sizes), 8))
+    assert a.ark_sizes() == parts and [f["offset"] for f in a.files()] == offs
+    a.enable_part_cipher(True, 1)
+    out = str(tmp_path) + "/"
+    before = modgpu.path_stats()
+    a.save(out, "main_ps4.hdr")
+    after = modgpu.path_stats()
+    assert after["scalar_calls"] == 0 and after["gpu_bytes"] - before["gpu_bytes"] >= data.size
+    plain = AH.serialise(names, sizes, offs, parts, a.ark_paths(), True)
+    assert len(plain) > (4 << 20)
+    want = np.frombuffer(plain, dtype=np.uint8).copy()
+    assert oracle.hdr_encrypt(want, True) == 0
+    assert np.array_equal(np.fromfile(out + "main_ps4.hdr", dtype=np.uint8), want)
+    off = 0
+    for path, size in zip(a.ark_paths(), parts):
+        assert size > (350 << 20)
+        got = np.fromfile(out + path, dtype=np.uint8)
+        assert got.size == size
+        oracle.cycle(got, oracle.KEY_PS4)  # decrypt on the CPU: must give the raw slice back
+        assert np.array_equal(got, data[off:off + size]), path
+        off += size
+    a.close()
+    b = host.Ark().load(out + "main_ps4.hdr")
+    b.enable_part_cipher(True, 1)
+    b.load_data()
+    assert np.array_equal(b.data(), data)
+    assert [(f["name"], f["size"], f["offset"]) for f in b.files()][:1000] == \
+        [(f["name"], f["size"], f["offset"]) for f in AH.parse(plain)["files"]][:1000]
+    b.close()
+
+
+def _tree_digest(root):
+    import hashlib
+    out = {}
+    for r, _, fs in os.walk(root):
+        for f in fs:
+            p = os.path.join(r, f)
+            out[os.path.relpath(p, root)] = hashlib.sha256(open(p, "rb").read()).hexdigest()
+    return out
+
+
+def test_config5_eight_workers_aliased(host, oracle, tmp_path, header_cwd):
+    """BASELINE config 5 in its 8-GPU form, rehearsed on one GPU: decrypt -> unpack -> repack -> encrypt with the
+    part cipher on and `-gpus 8` over MODGPU_DEVICE_ALIAS=8 (8 worker threads, 8 staging contexts).  Output must be
+    byte-identical to the 1-worker run, and every encrypted part must decrypt (oracle) to the raw slice."""
+    host.select_platform(True)
+    names, sizes, data = synth(1200, 31, max_size=120_000)
+    first = str(tmp_path / "first") + "/"
+    os.makedirs(first)
+    a = host.Ark()
+    a.construct_from_table(names, sizes, 8, "main_ps4")
+    a.build_from_memory(data)
+    a.enable_part_cipher(True, 1)
+    a.save(first, "main_ps4.hdr")
+    paths, parts = a.ark_paths(), a.ark_sizes()
+    a.close()
+    outs = {}
+    for workers in (1, 8):
+        env = dict(os.environ, MODGPU_DEVICE_ALIAS=str(workers))
+        unpacked, packed = str(tmp_path / f"u{workers}"), str(tmp_path / f"p{workers}")
+        os.makedirs(packed)
+        r = subprocess.run([EXE, "-cryptparts", "-gpus", str(workers), "-unpack", first, unpacked], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+        r = subprocess.run([EXE, "-cryptparts", "-gpus", str(workers), "-pack", first, unpacked, packed], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+        outs[workers] = (_tree_digest(unpacked), _tree_digest(packed))
+    assert outs[1] == outs[8]
+    offs = np.cumsum([0] + sizes)
+    for k in (0, 1, 599, 1199):
+        assert np.array_equal(np.fromfile(os.path.join(str(tmp_path / "u8"), names[k]), dtype=np.uint8), data[offs[k]:offs[k] + sizes[k]])
+    # the repacked archive: header loads, parts are ciphertext whose oracle-decryption holds every file at its offset
+    b = host.Ark().load(str(tmp_path / "p8") + "/main_ps4.hdr")
+    raw = np.concatenate([oracle.cycle(np.fromfile(os.path.join(str(tmp_path / "p8"), p), dtype=np.uint8), oracle.KEY_PS4) for p in b.ark_paths()])
+    by_name = dict(zip(names, zip(offs, sizes)))
+    for f in b.files():
+        o, s_ = by_name[f["name"]]
+        assert f["size"] == s_ and np.array_equal(raw[f["offset"]:f["offset"] + s_], data[o:o + s_]), f["name"]
+    b.close()
