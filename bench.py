@@ -24,38 +24,81 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Read once when libmodgpu.so is loaded: forbids the library's host loop, so that nothing this script
+# times or checks can have been computed anywhere but on the GPU (the run fails instead).
+os.environ["MODGPU_REQUIRE_GPU"] = "1"
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sample_bytes):
     """The reference's single-thread loop on this node's host cores, timed on a bounded sample
-    (encrypt + decrypt of `sample_bytes`).  Uses the compiled reference (oracle/_ref) when its
-    prebuilt library travelled with the repo, else our C restatement of it (the oracle)."""
+    (encrypt + decrypt of `sample_bytes`), the thread pinned to one core.  Uses the compiled
+    reference (oracle/_ref) when its prebuilt library travelled with the repo, else our C restatement
+    of it (the oracle).  This is the only place bench.py touches oracle/ -- as the thing timed beside
+    the GPU, never as the thing measured in `value`."""
     from oracle import oracle as O
     buf = O.splitmix_bytes(sample_bytes, 7)
     kind = "reference" if O.have_ref() else "port"
     fn = O.ref_cycle if kind == "reference" else O.cycle
-    fn(buf[:1 << 16].copy(), O.KEY_PS4)  # load + warm
-    t0 = time.perf_counter()
-    fn(buf, O.KEY_PS4)
-    fn(buf, O.KEY_PS4)
-    dt = time.perf_counter() - t0
-    return {"value": round(2 * sample_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
-            "sample": f"{sample_bytes >> 20} MiB part, encrypt+decrypt (2 passes), 1 thread, {dt:.1f} s; "
-                      f"host has {os.cpu_count()} logical cores"}
-
-
-def load_traffic(n_bytes):
-    """HBM bytes per launch from the committed PMC summary (profiles/), if one exists for this size."""
+    pinned_to = None
+    old_affinity = None
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as f:
+        old_affinity = os.sched_getaffinity(0)
+        pinned_to = max(old_affinity)  # away from core 0, which takes most interrupts
+        os.sched_setaffinity(0, {pinned_to})
+    except (AttributeError, OSError):
+        pinned_to = None
+    try:
+        fn(buf[:1 << 16].copy(), O.KEY_PS4)  # load + warm
+        t0 = time.perf_counter()
+        fn(buf, O.KEY_PS4)
+        fn(buf, O.KEY_PS4)
+        dt = time.perf_counter() - t0
+    finally:
+        if old_affinity is not None:
+            try:
+                os.sched_setaffinity(0, old_affinity)
+            except OSError:
+                pass
+    return {"value": round(2 * sample_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
+            "cpu_model": cpu_model(), "pinned_to_core": pinned_to, "host_logical_cores": os.cpu_count(),
+            "sample": f"{sample_bytes >> 20} MiB part, encrypt+decrypt (2 passes), 1 thread"
+                      f"{'' if pinned_to is None else f' pinned to core {pinned_to}'}, {dt:.1f} s"}
+
+
+def load_traffic(n_bytes, kernel, source_hash):
+    """HBM bytes per launch from the committed PMC summary (profiles/pmc_summary.json) -- but only if that
+    summary was taken on THIS device code (same kernel-source hash, same instantiation, same part size).
+    Counter passes cannot run inside a timed bench, so `traffic` is a replayed figure; `traffic_source`
+    says which profile it is, and anything that does not match the loaded library yields null.
+    Returns (traffic, traffic_source)."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        with open(path) as f:
             s = json.load(f)
-        if int(s.get("part_bytes", -1)) == n_bytes:
-            return s.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
-        pass
-    return None
+        return None, "no committed PMC summary"
+    tag = s.get("tag", "?")
+    if int(s.get("part_bytes", -1)) != n_bytes:
+        return None, f"profiles/{tag} PMC is for part_bytes={s.get('part_bytes')}, not measured for this size"
+    if not source_hash or s.get("kernel_source_hash") != source_hash:
+        return None, f"profiles/{tag} PMC was taken on other kernel sources ({str(s.get('kernel_source_hash'))[:12]}... vs loaded {str(source_hash)[:12]}...)"
+    if kernel not in str(s.get("cycle_kernel", "")):
+        return None, f"profiles/{tag} PMC was taken on {s.get('cycle_kernel')}"
+    return s.get("hbm_bytes_per_launch"), (f"replayed from profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                           f"separate passes, same kernel-source hash {source_hash[:12]}...)")
 
 
 def main():
@@ -136,6 +179,7 @@ def main():
         print(f"[rank {rank}] steps done+synced at {t_sync*1e3:.3f} ms, after trailing barrier {dt*1e3:.3f} ms", file=sys.stderr)
     dt = sharding.max_over_ranks(dt, red_dev)
     ms_per_launch = sharding.max_over_ranks(ms_per_launch, red_dev)
+    launch = M.last_launch()  # what the library launched for this size, straight from its planner
 
     # post-run checks (outside the timed region; no oracle code here -- committed golden DATA only):
     # an even number of passes must give the original bytes back (involution), and after one more
@@ -170,7 +214,8 @@ def main():
     if rank == 0:
         total_bytes = float(world) * a.steps * 2 * n
         achieved = 2.0 * n / (ms_per_launch * 1e-3) / 1e9  # read + write per launch
-        traffic = load_traffic(n)
+        traffic, traffic_source = load_traffic(n, launch["kernel"], M.kernel_source_hash())
+        stats = M.path_stats()
         out = {
             "metric": "GB/s encrypt+decrypt over synthetic .ark parts; % HBM peak at 1/2/4/8 GPU",
             "value": round(total_bytes / dt / 1e9, 2),
@@ -184,11 +229,14 @@ def main():
                                    f"HBM-resident, key {a.key:#010x}",
                        "part_bytes": n, "passes_per_step": 2, "parallelism": f"parts{world}",
                        "value_counts": "payload bytes cycled per second (HBM read+write traffic is 2x)",
-                       "bit_exact_check": ("pass" if n_ok == world else "FAIL") + f" (involution + {checked} golden keystream samples per rank)"},
+                       "bit_exact_check": ("pass" if n_ok == world else "FAIL") + f" (involution + {checked} golden keystream samples per rank)",
+                       "engine": f"gfx950 kernel only (MODGPU_REQUIRE_GPU=1): {stats['gpu_launches']} launches, "
+                                 f"{stats['scalar_calls']} host-loop calls on rank 0"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "modgpu_cycle_kernel<8, 1024, 1, 2, 0, 16, 3>", "ms_per_launch": round(ms_per_launch, 4),
-                         "algorithmic_bytes_per_launch": 2 * n},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": launch["kernel"], "grid": launch["grid"], "block": launch["block"],
+                         "chunk_bytes": launch["chunk_bytes"], "kernel_source_hash": M.kernel_source_hash(),
+                         "ms_per_launch": round(ms_per_launch, 4), "algorithmic_bytes_per_launch": 2 * n},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample_bytes)

@@ -18,6 +18,8 @@ struct CycleArgs {
                          // addresses, so the first one starts `lead` bytes before the body and is masked there
     uint32_t base_head;  // state of the buffer's first byte
     uint32_t base_tail;  // state of the first tail byte
+    uint64_t *trace;     // nullptr in the product.  tools/tune_cycle's TRACE instantiation writes per-workgroup
+                         // timestamps here (wall_clock64, 100 MHz): [blk*32+0] start, [+1+k] end of trip k, [+31] XCC id
 };
 
 // Launch shapes.  A workgroup trip covers `chunk_bytes` contiguous bytes; the grid strides over

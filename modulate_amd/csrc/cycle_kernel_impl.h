@@ -122,7 +122,11 @@ constexpr int AUX_SC1 = 16; // system-coherent / write-through -- best for the s
 // bytes left in the body, capped at the chunk) drops the lanes past the end of a ragged last
 // chunk -- there is no tail branch.  Loads are `nt`, stores `sc1` (SAUX): measured best per direction
 // (profiles/r01_ubench_copy_policies.txt).
-template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = AUX_SC1, int SYNC = 0>
+// TRACE = 1 (tools/tune_cycle only): lane 0 of every workgroup records when it started and when each trip's
+//         stores had been issued (CycleArgs::trace)
+// LDSW  = 1 (tools/tune_cycle only; the north_star's "LDS as a write-combine stage", measured, not shipped):
+//         each trip's finished words go registers -> LDS -> registers before the store burst
+template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = AUX_SC1, int SYNC = 0, int TRACE = 0, int LDSW = 0>
 __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
 {
     static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
@@ -130,6 +134,16 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
     constexpr uint32_t SUB = BLOCK * lcg::WORD;                 // bytes per sub-step (one load per lane)
     const uint32_t tid = threadIdx.x;
     const uint32_t blk = blockIdx.x;
+    [[maybe_unused]] uint32_t trip = 0;
+    [[maybe_unused]] auto stamp = [&](uint32_t slot) {
+        if constexpr (TRACE != 0) {
+            if (tid == 0 && slot < 31) a.trace[blk * 32 + slot] = wall_clock64();
+        }
+    };
+    if constexpr (TRACE != 0) {
+        if (tid == 0) a.trace[blk * 32 + 31] = __builtin_amdgcn_s_getreg((20 | (0 << 6) | (3 << 11))); // HW_REG_XCC_ID[3:0]
+        stamp(0);
+    }
 
     // ---- ragged edges: < 16 bytes before / after the aligned body, done bytewise by block 0
     if (blk == 0 && tid < 32) {
@@ -231,6 +245,17 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
                 s[u] = mulmod_canon2(s[u], stride2);
             }
         }
+        if constexpr (LDSW != 0) {
+            // write-combine stage: sub-step u's 16 KiB (BLOCK x 16 B) sits contiguously in LDS exactly as it
+            // will sit in HBM, then every lane reads its own word back.  Nothing is re-ordered -- the
+            // register layout is already the store layout -- so this measures the stage's price.
+            __shared__ u32x4 stage[U * BLOCK];
+#pragma unroll
+            for (int u = 0; u < U; ++u) stage[u * BLOCK + tid] = d[u];
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = stage[u * BLOCK + tid];
+        }
         if constexpr ((SYNC & 2) != 0 && PIPE != 0) {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -242,6 +267,7 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
                     __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
             } else __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
         }
+        stamp(++trip);
     };
 
     if constexpr (PIPE == 0) {

@@ -17,7 +17,18 @@ def find(root, pat):
 
 def main():
     root, tag = sys.argv[1], sys.argv[2]
-    out = {"tag": tag}
+    part_bytes = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 32
+    out = {"tag": tag, "part_bytes": part_bytes,
+           "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py ; rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE "
+                      f"(separate passes) -- python3 bench.py --no-cpu-baseline  (tools/profile.sh {tag})"}
+    # identity of the device code these figures belong to: bench.py replays `traffic` only for the same hash
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        import modulate_amd as M
+        out["kernel_source_hash"] = M.kernel_source_hash()
+    except Exception as e:  # noqa: BLE001
+        out["kernel_source_hash"] = None
+        out["kernel_source_hash_error"] = str(e)
     # ---- kernel trace
     per = defaultdict(list)
     for f in find(os.path.join(root, "trace"), "*kernel_trace.csv"):
