@@ -25,8 +25,8 @@ int modgpu_time_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t st
 /* The launch the calling thread made last (any entry point), as the library planned it. */
 typedef struct modgpu_launch_info {
     const char *kernel;   /* the instantiation's name as rocprofv3 prints it, e.g.
-                             "modgpu_cycle_kernel<8, 1024, 1, 2, 0, 16, 3>"; static storage      */
-    int variant;          /* 0 = small shape, 1 = streaming shape, 2 = mid-size streaming shape   */
+                             "modgpu_cycle_queue_kernel<8, 1024, 1, 16, 0>"; static storage      */
+    int variant;          /* 0 = small shape, 1 = streaming shape (static chunk map), 2 = streaming shape fed by the work queue */
     uint32_t grid;        /* workgroups                                                           */
     uint32_t block;       /* threads per workgroup                                                */
     uint32_t chunk_bytes; /* bytes one workgroup trip covers                                      */
@@ -39,10 +39,15 @@ int modgpu_last_launch(modgpu_launch_info_t *out);
  * even trip counts and ragged ends on buffers of a few MiB. */
 void modgpu_debug_set_launch(int variant, uint32_t grid_cap);
 
-/* How modgpu_cycle_host treats a pinned caller buffer: 0 = library default, 1 = DMA pipeline
+/* How modgpu_cycle_host treats a pinned caller buffer: 0 = library default (= 2), 1 = DMA ring
  * (H2D -> kernel in HBM -> D2H straight from / to the caller's pages), 2 = one kernel over PCIe on
- * the pages themselves.  Both give the same bytes; tools/sweep_hostpath.py times them. */
+ * the pages themselves.  Both give the same bytes; tools/sweep_pinned.py times them. */
 void modgpu_debug_set_pinned_mode(int mode);
+
+/* How a staged chunk (pageable memory or a file, copied into a pinned slot) is cycled: 0 = library
+ * default, 1 = H2D -> kernel in HBM -> D2H, 2 = the kernel works on the pinned slot across PCIe (no DMA
+ * submissions, no device slot).  Same bytes; tools/sweep_pinned.py times them. */
+void modgpu_debug_set_staged_mode(int mode);
 
 /* Identity of the device code this library carries: hex SHA-256 over the kernel sources it was
  * built from (cycle_kernel_impl.h, cycle_kernel.hip, cycle_kernel.h, lcg.h), fixed at build time.

@@ -66,6 +66,7 @@ TESTING_EXPORTS = {
     "modgpu_last_launch": (_int, [ctypes.POINTER(LaunchInfo)]),
     "modgpu_debug_set_launch": (None, [_int, ctypes.c_uint32]),
     "modgpu_debug_set_pinned_mode": (None, [_int]),
+    "modgpu_debug_set_staged_mode": (None, [_int]),
     "modgpu_kernel_source_hash": (ctypes.c_char_p, []),
 }
 
@@ -154,17 +155,23 @@ def last_launch():
             "chunk_bytes": info.chunk_bytes, "bytes": info.bytes}
 
 
-SHAPES = {None: -1, "auto": -1, "small": 0, "large": 1}
+SHAPES = {None: -1, "auto": -1, "small": 0, "large": 1, "queue": 2}
 
 
 def debug_set_launch(shape=None, grid_cap=0):
-    """Test hook: force the launch shape ("small" / "large" / None = by size) and cap the grid."""
+    """Test hook: force the launch shape ("small" / "large" = streaming, static chunk map / "queue" = streaming,
+    work queue / None = by size) and cap the grid."""
     lib().modgpu_debug_set_launch(SHAPES[shape], grid_cap or 0)
 
 
 def debug_set_pinned_mode(mode=0):
     """Test hook: 0 default, 1 DMA pipeline, 2 kernel over PCIe, for pinned caller buffers."""
     lib().modgpu_debug_set_pinned_mode(mode)
+
+
+def debug_set_staged_mode(mode=0):
+    """Test hook: 0 default, 1 DMA, 2 kernel over PCIe on the pinned slot, for staged (pageable / file) chunks."""
+    lib().modgpu_debug_set_staged_mode(mode)
 
 
 def kernel_source_hash():

@@ -18,6 +18,7 @@ struct CycleArgs {
                          // addresses, so the first one starts `lead` bytes before the body and is masked there
     uint32_t base_head;  // state of the buffer's first byte
     uint32_t base_tail;  // state of the first tail byte
+    uint32_t *queue;     // work-queue shape only: {ticket counter, workgroups done}, both 0 at launch and 0 again at exit
     uint64_t *trace;     // nullptr in the product.  tools/tune_cycle's TRACE instantiation writes per-workgroup
                          // timestamps here (wall_clock64, 100 MHz): [blk*32+0] start, [+1+k] end of trip k, [+31] XCC id
 };
@@ -27,8 +28,9 @@ struct CycleArgs {
 enum CycleVariant : int {
     CYCLE_SMALL = 0, // 256 threads x 1 word : 4 KiB chunks, headers and other small buffers
     CYCLE_LARGE = 1, // 1024 threads x 8 words, software-pipelined, workgroup-synchronous bursts: 128 KiB chunks
+    CYCLE_QUEUE = 2, // the same shape, chunks handed out by a ticket counter (needs CycleArgs::queue; < 2^24 chunks)
 };
-constexpr int kCycleVariants = 2;
+constexpr int kCycleVariants = 3;
 uint32_t modgpu_variant_chunk_bytes(int variant);
 uint32_t modgpu_variant_block(int variant);
 // The instantiation's name as a profiler prints it ("modgpu_cycle_kernel<8, 1024, 1, 2, 0, 16, 3>"),

@@ -43,19 +43,48 @@ template <int U, int BLOCK, int ALG, int PIPE, int SAUX, int SYNC> struct Shape 
         return buf;
     }
 };
+// the same streaming shape fed from a ticket counter instead of the static chunk map
+template <int U, int BLOCK, int ALG, int SAUX> struct QueueShape {
+    static constexpr uint32_t chunk = (uint32_t)U * BLOCK * lcg::WORD;
+    static constexpr uint32_t block = BLOCK;
+    static void launch(const CycleArgs &a, uint32_t grid, hipStream_t stream)
+    {
+        hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, ALG, SAUX, 0>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    }
+    static const char *name()
+    {
+        static char buf[96];
+        static const int n = std::snprintf(buf, sizeof buf, "modgpu_cycle_queue_kernel<%d, %d, %d, %d, 0>", U, BLOCK, ALG, SAUX);
+        (void)n;
+        return buf;
+    }
+};
 // one word per thread, 256 threads, no pipeline: launch-latency-bound sizes
 using Small = Shape<1, 256, 1, 0, AUX_SC1, 0>;
 // U=8 words x 1024 threads, SDWA keystream, pipelined + loads-first, sc1 stores, workgroup-synchronous bursts
 using Large = Shape<8, 1024, 1, 2, AUX_SC1, 3>;
+// 64 KiB chunks: measured best under the queue (profiles/r02_tune_cycle_queue_shapes.txt): 128 KiB balances
+// coarser, 32 KiB and below saturate the ticket counter (~80 tickets/us chip-wide)
+using Queue = QueueShape<4, 1024, 1, AUX_SC1>;
 } // namespace
 
-uint32_t modgpu_variant_chunk_bytes(int variant) { return variant == CYCLE_LARGE ? Large::chunk : Small::chunk; }
-uint32_t modgpu_variant_block(int variant) { return variant == CYCLE_LARGE ? Large::block : Small::block; }
-const char *modgpu_variant_kernel_name(int variant) { return variant == CYCLE_LARGE ? Large::name() : Small::name(); }
+uint32_t modgpu_variant_chunk_bytes(int variant)
+{
+    return variant == CYCLE_QUEUE ? Queue::chunk : variant == CYCLE_LARGE ? Large::chunk : Small::chunk;
+}
+uint32_t modgpu_variant_block(int variant)
+{
+    return variant == CYCLE_QUEUE ? Queue::block : variant == CYCLE_LARGE ? Large::block : Small::block;
+}
+const char *modgpu_variant_kernel_name(int variant)
+{
+    return variant == CYCLE_QUEUE ? Queue::name() : variant == CYCLE_LARGE ? Large::name() : Small::name();
+}
 
 hipError_t modgpu_launch_cycle(const CycleArgs &a, int variant, uint32_t grid, hipStream_t stream)
 {
-    if (variant == CYCLE_LARGE) Large::launch(a, grid, stream);
+    if (variant == CYCLE_QUEUE) Queue::launch(a, grid, stream);
+    else if (variant == CYCLE_LARGE) Large::launch(a, grid, stream);
     else Small::launch(a, grid, stream);
     return hipGetLastError();
 }

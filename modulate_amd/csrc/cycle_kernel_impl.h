@@ -100,6 +100,27 @@ template <int ALG> __device__ __forceinline__ u32x4 cycle_word(u32x4 d, uint32_t
 // One byte at state s (head / tail bytes outside the aligned body).
 __device__ __forceinline__ uint8_t cycle_byte(uint8_t d, uint32_t s) { return (uint8_t)~(d ^ (uint8_t)s); }
 
+// < 16 bytes before / after the aligned body, done bytewise by 32 lanes of one workgroup
+__device__ __forceinline__ void cycle_edges(const CycleArgs &a, uint32_t tid)
+{
+    if (tid < a.head_n) {
+        uint32_t s = a.base_head;
+        for (uint32_t j = 0; j < tid; ++j) s = mulmod_canon(s, lcg::A);
+        a.head_ptr[tid] = cycle_byte(a.head_ptr[tid], s);
+    } else if (tid >= 16 && tid < 32 && tid - 16 < a.tail_n) {
+        uint32_t t = tid - 16;
+        uint32_t s = a.base_tail;
+        for (uint32_t j = 0; j < t; ++j) s = mulmod_canon(s, lcg::A);
+        a.tail_ptr[t] = cycle_byte(a.tail_ptr[t], s);
+    }
+}
+
+// a^(CHUNK * c) by the three bytes of a chunk index c < 2^24 (queue kernel: a workgroup's next chunk is
+// whatever the ticket counter hands it, so it jumps from the chunk index instead of striding)
+template <uint32_t CHUNK> __constant__ lcg::Table<256> c_chunk_pow0 = lcg::make_pow_table<256>(CHUNK);
+template <uint32_t CHUNK> __constant__ lcg::Table<256> c_chunk_pow1 = lcg::make_pow_table<256>((uint64_t)CHUNK << 8);
+template <uint32_t CHUNK> __constant__ lcg::Table<256> c_chunk_pow2 = lcg::make_pow_table<256>((uint64_t)CHUNK << 16);
+
 enum : int { MODE_FULL = 0, MODE_COPY = 1, MODE_COMPUTE = 2 };
 constexpr int AUX_NT = 2;   // buffer cache-policy bit: non-temporal (streaming) -- best for the loads (7.0 vs 6.4 TB/s read-only)
 constexpr int AUX_SC1 = 16; // system-coherent / write-through -- best for the stores (6.3 vs 5.9 TB/s write-only)
@@ -146,18 +167,7 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
     }
 
     // ---- ragged edges: < 16 bytes before / after the aligned body, done bytewise by block 0
-    if (blk == 0 && tid < 32) {
-        if (tid < a.head_n) {
-            uint32_t s = a.base_head;
-            for (uint32_t j = 0; j < tid; ++j) s = mulmod_canon(s, lcg::A);
-            a.head_ptr[tid] = cycle_byte(a.head_ptr[tid], s);
-        } else if (tid >= 16 && tid - 16 < a.tail_n) {
-            uint32_t t = tid - 16;
-            uint32_t s = a.base_tail;
-            for (uint32_t j = 0; j < t; ++j) s = mulmod_canon(s, lcg::A);
-            a.tail_ptr[t] = cycle_byte(a.tail_ptr[t], s);
-        }
-    }
+    if (blk == 0 && tid < 32) cycle_edges(a, tid);
 
     // ---- aligned body.  Chunks sit on ABSOLUTE chunk-aligned addresses (a base that is only 16-byte
     // aligned costs 15 % otherwise: every 1 KiB wave access would straddle 128-byte lines), so the
@@ -294,6 +304,152 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
             process_store(d1, off);
             off += step;
             if (off >= end) break;
+        }
+    }
+}
+
+// ---- the streaming kernel with a work queue ---------------------------------------------------------
+// Same lane layout, bursts, cache policies and arithmetic as modgpu_cycle_kernel<U, BLOCK, ALG, 2, MODE_FULL,
+// SAUX, 3> above; what differs is WHICH chunk a workgroup takes next.  With the static map (b, b+G, b+2G ...)
+// every workgroup does the same number of trips, but the CUs are not equally fast: the workgroups of every
+// other XCD take ~9.6 us per trip, the rest ~11 us (profiles/r02_trace_static_schedule.txt), so half the
+// chip idles at the end of every launch while the other half finishes.  Here a workgroup's first three
+// chunks are static (b, b+G, b+2G: no start-up latency) and every later one is a ticket from a global
+// counter, fetched a full trip before it is needed, so fast CUs simply take more chunks and all of them
+// finish within one trip of each other.
+//
+// Ticket hand-off inside a workgroup: lane 0 issues the returning atomic right after a trip's second barrier
+// (in front of that trip's store burst, so waiting for it later never waits for those stores), publishes the
+// value through one LDS word before the NEXT trip's second barrier, and every wave reads it after that
+// barrier.  a.queue[0] is the ticket counter, a.queue[1] counts workgroups that are done; the last one out
+// zeroes both, so the pair is clean for the next launch without a memset.
+template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int TRACE = 0>
+__global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
+{
+    static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
+    constexpr uint32_t CHUNK = (uint32_t)U * BLOCK * lcg::WORD;
+    constexpr uint32_t SUB = BLOCK * lcg::WORD;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t blk = blockIdx.x;
+    const uint32_t G = gridDim.x;
+    __shared__ uint32_t q_next;
+    [[maybe_unused]] uint32_t trip = 0;
+    [[maybe_unused]] auto stamp = [&](uint32_t slot) {
+        if constexpr (TRACE != 0) {
+            if (tid == 0 && slot < 31) a.trace[blk * 32 + slot] = wall_clock64();
+        }
+    };
+    if constexpr (TRACE != 0) {
+        if (tid == 0) a.trace[blk * 32 + 31] = __builtin_amdgcn_s_getreg((20 | (0 << 6) | (3 << 11)));
+        stamp(0);
+    }
+    if (blk == 0 && tid < 32) cycle_edges(a, tid);
+
+    const uint64_t lead = a.lead;
+    const uint64_t end = lead + a.body_words * lcg::WORD;
+    const uint32_t n_chunks = (uint32_t)((end + CHUNK - 1) / CHUNK); // host: < 2^24
+    uint8_t *const origin = static_cast<uint8_t *>(a.body) - lead;
+    const uint32_t voff = tid * lcg::WORD;
+
+    // state of this lane's word 0 in chunk 0; chunk c multiplies it by a^(CHUNK*c)
+    const uint32_t lane0 = mulmod_canon(mulmod_canon(a.base_body, c_tile_lo.v[tid >> 8]), c_lane_pow.v[tid & 255]);
+    auto states = [&](uint32_t c, uint32_t(&s)[U]) {
+        uint32_t p = mulmod_canon(c_chunk_pow0<CHUNK>.v[c & 255], c_chunk_pow1<CHUNK>.v[(c >> 8) & 255]);
+        p = mulmod_canon(p, c_chunk_pow2<CHUNK>.v[(c >> 16) & 255]);
+        s[0] = mulmod_canon(lane0, p);
+#pragma unroll
+        for (int u = 1; u < U; ++u) s[u] = mulmod_canon(s[u - 1], lcg::kTileLo.v[BLOCK / 256]);
+    };
+
+    // chunk 0 is cut at the front when the body is not chunk-aligned: workgroup 0 peels it off (see
+    // modgpu_cycle_kernel), and chunk numbering for everybody starts at 1
+    const uint32_t first = lead != 0 ? 1u : 0u;
+    if (blk == 0 && lead != 0) {
+        const uint64_t inside = end < CHUNK ? end - lead : CHUNK - lead;
+        auto r = __builtin_amdgcn_make_buffer_rsrc(static_cast<uint8_t *>(a.body), 0, (int)inside, 0x00020000);
+        uint32_t su = lane0;
+#pragma unroll 1
+        for (uint32_t u = 0; u < (uint32_t)U; ++u) {
+            const uint32_t o = voff + u * SUB - (uint32_t)lead;
+            u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, AUX_NT);
+            d = cycle_word<ALG>(d, su);
+            __builtin_amdgcn_raw_buffer_store_b128(d, r, o, 0, SAUX);
+            su = mulmod_canon(su, lcg::kTileLo.v[BLOCK / 256]);
+        }
+    }
+
+    auto rsrc_at = [&](uint32_t c) {
+        const uint64_t o = (uint64_t)c * CHUNK;
+        const uint64_t left = o < end ? end - o : 0; // a chunk past the end: zero-size descriptor, loads give 0, stores drop
+        return __builtin_amdgcn_make_buffer_rsrc(origin + o, 0, (int)(left < CHUNK ? left : CHUNK), 0x00020000);
+    };
+    auto load = [&](u32x4(&d)[U], uint32_t c) {
+        auto r = rsrc_at(c);
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, AUX_NT);
+    };
+    // Lane 0's ticket traffic.  The returning atomic is a plain compiler-visible atomic, so the compiler counts it
+    // in its own s_waitcnt vmcnt(N) bookkeeping and waits for the value only where it is published, a trip
+    // later.  This needs the TU built with  -mllvm -amdgpu-atomic-optimizer-strategy=None : the default
+    // "atomic optimizer" rewrites it into a wave-aggregated atomic followed at once by s_waitcnt vmcnt(0),
+    // i.e. the wave would sit out the atomic's round trip and every load it has in flight, each trip.
+    // The LDS word is accessed with ds_write / ds_read in assembly: a volatile C++ access to a __shared__
+    // variable becomes a FLAT access, which waits on vmcnt as well as lgkmcnt.
+    uint32_t pending = 0; // lane 0: the ticket in flight
+    const uint32_t q_next_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&q_next;
+    const uint32_t one = 1u;
+    // one trip: chunk c's words are in d; compute, publish last trip's ticket, barrier, fetch a ticket, store burst
+    auto process_store = [&](u32x4(&d)[U], uint32_t c, bool publish) {
+        auto r = rsrc_at(c);
+        uint32_t s[U];
+        states(c, s);
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = cycle_word<ALG>(d[u], s[u]);
+        if (publish && tid == 0) // (the LDS write has landed before the barrier releases the readers)
+            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(q_next_lds), "v"(pending) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) pending = __hip_atomic_fetch_add(a.queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
+        stamp(++trip);
+    };
+    auto take_published = [&]() { // every lane, after the trip's second barrier
+        uint32_t t;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(q_next_lds) : "memory");
+        return first + 3u * G + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    };
+
+    uint32_t c0 = first + blk, c1 = c0 + G, c2 = c1 + G; // static prefix; tickets continue from first + 3G
+    if (c0 < n_chunks) {
+        u32x4 d0[U], d1[U];
+        load(d0, c0);
+        bool publish = false; // the first trip has no ticket to publish yet: c2 is static
+        while (true) {
+            __builtin_amdgcn_s_barrier();
+            load(d1, c1);
+            __builtin_amdgcn_sched_barrier(0);
+            process_store(d0, c0, publish);
+            c0 = c1;
+            c1 = c2;
+            if (publish) c1 = take_published();
+            publish = true;
+            if (c0 >= n_chunks) break;
+            __builtin_amdgcn_s_barrier();
+            load(d0, c1);
+            __builtin_amdgcn_sched_barrier(0);
+            process_store(d1, c0, true);
+            c0 = c1;
+            c1 = take_published();
+            if (c0 >= n_chunks) break;
+        }
+    }
+    // leave: this workgroup's ticket atomics have all returned; the last workgroup out resets the pair
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(a.queue + 1, 1u) == G - 1) {
+            __hip_atomic_store(a.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

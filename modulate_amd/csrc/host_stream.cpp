@@ -4,11 +4,13 @@
 //
 // Three routes, picked per call:
 //
-//   pinned, large     the caller's pages are page-locked (modgpu_host_alloc / modgpu_host_register):
-//                     chunk i goes  H2D (DMA straight from the caller's pages) -> kernel in HBM ->
-//                     D2H (DMA straight back), a ring of device slots on their own streams so both
-//                     DMA directions and the kernels overlap.  No host copy, no host threads.
-//                     (Alternative, same bytes: one kernel over PCIe on the pages themselves.)
+//   pinned            the caller's pages are page-locked (modgpu_host_alloc): ONE kernel launch reads and
+//                     writes them across PCIe where they lie -- no host copy, no DMA submissions, no
+//                     device slots, no host threads.  50 GB/s of payload at 64 MiB .. 4 GiB, each byte
+//                     crossing the link twice (profiles/r02_sweep_pinned_routes.txt).  (Alternative, same
+//                     bytes, slower at 26-29 GB/s and kept selectable: chunked H2D -> kernel in HBM -> D2H
+//                     straight from / to the pages through a ring of device slots.)  When only one side of a
+//                     file stream is pinned memory, that side is DMA'd directly and the file side staged.
 //   pageable, large   memcpy -> pinned slot -> H2D -> kernel -> D2H -> pinned slot -> memcpy, spread
 //                     over kPipes independent pipelines (host thread + two slots each): one thread
 //                     copies pageable<->pinned at 22 GB/s, four at 73 (profiles/r01_ubench_hostpath.txt).
@@ -32,6 +34,7 @@
 namespace modgpu {
 
 std::atomic<int> g_pinned_mode{0};
+std::atomic<int> g_staged_mode{0};
 
 namespace {
 
@@ -127,6 +130,7 @@ struct Job {
     uint64_t n, chunk;
     int32_t key;
     uint64_t stream_off;
+    bool slot_kernel = false; // staged chunks are cycled in their pinned slot across PCIe (no DMA, no device slot)
     std::atomic<bool> touched{false};
 };
 
@@ -156,6 +160,13 @@ int run_pipe(Staging &s, int slot0, int ring, Job &j, uint64_t first, uint64_t s
         if (i < mine) {
             uint64_t off, len;
             span(first + i * stride, &off, &len);
+            if (j.slot_kernel) { // neither side is pinned caller memory: the slot itself is the device-visible copy
+                int rc = fill_slot(j.src, s.pinned[slot], off, len);
+                if (rc) return rc;
+                void *mapped = nullptr;
+                HIP_TRY(hipHostGetDevicePointer(&mapped, s.pinned[slot], 0));
+                return cycle_device_impl(mapped, len, j.key, j.stream_off + off, s.stream[slot], /*over_pcie=*/true);
+            }
             if (src_direct) {
                 HIP_TRY(hipMemcpyAsync(s.dev[slot], j.src.mem + off, len, hipMemcpyHostToDevice, s.stream[slot]));
             } else {
@@ -214,14 +225,16 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     // ---- kernel over PCIe: header-sized buffers (what the reference's three call sites pass, <= 512 KiB),
     // and pinned caller memory of any size when that mode is selected.  One launch + one sync; the
     // kernel reads and writes the pinned pages across PCIe itself (they are device-visible).
+    // (default for pinned memory: measured 50 GB/s of payload against 26-29 for the DMA ring below and
+    //  30 for the staged route, profiles/r02_sweep_pinned_routes.txt; mode 1 keeps the DMA ring selectable)
     const int mode = g_pinned_mode.load(std::memory_order_relaxed);
-    if (in_place && src_direct && !identity && (n <= kZeroCopyMax || mode == 2)) {
+    if (in_place && src_direct && !identity && (n <= kZeroCopyMax || mode != 1)) {
         rc = staging_reserve(s, 0, 1, 0, false, false);
         if (rc) return rc;
         void *mapped = nullptr;
         HIP_TRY(hipHostGetDevicePointer(&mapped, src.mem, 0));
         if (touched) *touched = true;
-        rc = cycle_device_impl(mapped, n, key, stream_off, s.stream[0]);
+        rc = cycle_device_impl(mapped, n, key, stream_off, s.stream[0], /*over_pcie=*/true);
         hipError_t e = hipStreamSynchronize(s.stream[0]);
         if (rc) return rc;
         if (e != hipSuccess) return fail_hip(e, "hipStreamSynchronize (kernel over PCIe)");
@@ -235,7 +248,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
         void *mapped = nullptr;
         HIP_TRY(hipHostGetDevicePointer(&mapped, s.pinned[0], 0));
         std::memcpy(s.pinned[0], src.mem, n);
-        rc = cycle_device_impl(mapped, n, key, stream_off, s.stream[0]);
+        rc = cycle_device_impl(mapped, n, key, stream_off, s.stream[0], /*over_pcie=*/true);
         hipError_t e = hipStreamSynchronize(s.stream[0]);
         if (rc) return rc;
         if (e != hipSuccess) return fail_hip(e, "hipStreamSynchronize (kernel over PCIe)");
@@ -252,6 +265,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     chunk = std::min<uint64_t>(chunk, kChunk);
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
     Job job{src, dst, n, chunk, key, stream_off};
+    job.slot_kernel = !src_direct && !dst_direct && g_staged_mode.load(std::memory_order_relaxed) == 2;
     int pipes, ring;
     if (all_direct && src.mem && dst.mem) { // no host work at all: one thread keeps a ring of slots busy
         pipes = 1;
@@ -260,7 +274,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
         pipes = (int)std::min<uint64_t>((uint64_t)kPipes, (n_chunks + 1) / 2); // a pipeline is worth >= 2 chunks
         ring = 2;
     }
-    rc = staging_reserve(s, 0, pipes * ring, chunk, true, !(src_direct && dst_direct));
+    rc = staging_reserve(s, 0, pipes * ring, chunk, !job.slot_kernel, !(src_direct && dst_direct));
     if (rc) return rc;
 
     if (pipes <= 1) {

@@ -145,6 +145,43 @@ uint32_t large_grid()
     }
     return cus[dev];
 }
+// Work-queue shape: every launch needs a {ticket, done} pair that is zero when it starts; the kernel's last
+// workgroup zeroes it again, so a per-device ring of pairs (one 64-byte line each), handed out round-robin,
+// is allocated and cleared once.  A pair is reused after kQueueRing later launches on that device.
+constexpr uint32_t kQueueRing = 256;
+struct QueueRing {
+    std::mutex mu;
+    uint32_t *base = nullptr; // kQueueRing lines of 16 words
+    std::atomic<uint32_t> next{0};
+};
+QueueRing g_queue_ring[kMaxDevices];
+
+// nullptr: no pair available right now (first use while the stream is being captured into a graph --
+// allocating there would break the capture -- or the allocation failed): the caller takes the static shape.
+uint32_t *queue_pair(hipStream_t stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    QueueRing &r = g_queue_ring[dev];
+    if (!r.base) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        std::lock_guard<std::mutex> lock(r.mu);
+        if (!r.base) {
+            uint32_t *p = nullptr;
+            if (hipMalloc(reinterpret_cast<void **>(&p), kQueueRing * 64) != hipSuccess || hipMemset(p, 0, kQueueRing * 64) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            r.base = p;
+        }
+    }
+    return r.base + (size_t)(r.next.fetch_add(1, std::memory_order_relaxed) % kQueueRing) * 16;
+}
+
 constexpr uint32_t kSmallGridMax = 16384u;   // 4 KiB chunks: grid * 1 tile <= 65536
 // Hand-over between the two shapes, measured warm and cold (profiles/r01_tune_cycle_sizes*.txt):
 // up to 256 MiB the one-shot 4 KiB-chunk grid wins (launch cost ~3 us vs ~9 us, and the buffer fits
@@ -153,7 +190,12 @@ constexpr uint64_t kLargeMin = (256ull << 20) + 1;
 
 // Splits [buf, buf+n) into <16 head bytes, an aligned body of 16-byte words and <16 tail bytes,
 // and computes the states that seed each piece.  key_res != 0.
-Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off)
+// Over PCIe (page-locked host memory): the link, not HBM, is the bound, and it is saturated by a few
+// dozen workgroups of the one-word shape; more only adds contention (profiles/r02_sweep_pinned_routes.txt:
+// 4 KiB chunks, grid <= 256: 50 GB/s of payload at 64 MiB .. 4 GiB; uncapped 46; the streaming shape 41-46).
+constexpr uint32_t kPcieGridMax = 256u;
+
+Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off, bool over_pcie, hipStream_t stream)
 {
     Plan p{};
     uintptr_t addr = reinterpret_cast<uintptr_t>(dev_buf);
@@ -175,16 +217,21 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
     a.base_tail = lcg::state_residue(key_res, o + head + (words * 16) % lcg::PERIOD);
 
     uint64_t body_bytes = words * 16;
-    p.variant = body_bytes >= kLargeMin ? CYCLE_LARGE : CYCLE_SMALL;
+    p.variant = body_bytes >= kLargeMin && !over_pcie ? CYCLE_QUEUE : CYCLE_SMALL;
     const int forced = g_force_variant.load(std::memory_order_relaxed);
     if (forced >= 0 && forced < kCycleVariants) p.variant = forced;
     uint64_t chunk = modgpu_variant_chunk_bytes(p.variant);
+    if (p.variant == CYCLE_QUEUE) { // needs a clean ticket pair and chunk indices that fit its 3-byte jump tables
+        a.queue = (body_bytes + chunk) / chunk + 4ull * 2048 < (1ull << 24) ? queue_pair(stream) : nullptr;
+        if (!a.queue) p.variant = CYCLE_LARGE;
+    }
     // chunks sit on absolute chunk-aligned addresses: the first starts `lead` bytes before the body,
     // and the kernel counts positions from there, so its base state is stepped back by a^(-lead)
     a.lead = (uint32_t)(reinterpret_cast<uintptr_t>(a.body) & (chunk - 1));
     a.base_body = lcg::mulmod(a.base_body, lcg::powmod(lcg::A, lcg::PERIOD - a.lead % lcg::PERIOD));
     uint64_t chunks = (a.lead + body_bytes + chunk - 1) / chunk;
     uint64_t cap = p.variant == CYCLE_SMALL ? kSmallGridMax : large_grid();
+    if (over_pcie) cap = std::min<uint64_t>(cap, kPcieGridMax);
     const uint32_t grid_cap = g_grid_cap.load(std::memory_order_relaxed);
     if (grid_cap >= 1 && grid_cap < cap) cap = grid_cap;
     p.grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(chunks, cap));
@@ -195,13 +242,13 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
 
 } // namespace
 
-int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off, hipStream_t stream)
+int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off, hipStream_t stream, bool over_pcie)
 {
     if (n == 0) return MODGPU_OK;
     if (!dev_buf) return fail(MODGPU_ERR_INVALID, "null device buffer");
     uint32_t key_res = lcg::key_residue(key);
     if (key_res == 0) return MODGPU_OK; // keystream is all zero (state sticks at m): identity
-    Plan p = plan_cycle(dev_buf, n, key_res, stream_off);
+    Plan p = plan_cycle(dev_buf, n, key_res, stream_off, over_pcie, stream);
     hipError_t e = modgpu_launch_cycle(p.args, p.variant, p.grid, stream);
     if (e != hipSuccess) return fail_hip(e, "cycle kernel launch");
     g_stats.gpu_launches.fetch_add(1, std::memory_order_relaxed);
@@ -564,6 +611,7 @@ void modgpu_debug_set_launch(int variant, uint32_t grid_cap)
 }
 
 void modgpu_debug_set_pinned_mode(int mode) { g_pinned_mode.store(mode, std::memory_order_relaxed); }
+void modgpu_debug_set_staged_mode(int mode) { g_staged_mode.store(mode, std::memory_order_relaxed); }
 
 const char *modgpu_kernel_source_hash(void) { return MODGPU_KERNEL_SOURCE_HASH; }
 

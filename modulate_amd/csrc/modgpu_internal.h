@@ -53,7 +53,10 @@ int select_device(int device);
 int resolve_device(int device, int *out);
 
 // ---- the launch (device already current) ----------------------------------------------------
-int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off, hipStream_t stream);
+// over_pcie: dev_buf is page-locked HOST memory the kernel reaches across PCIe -- planned with the shape
+// and grid that saturate the link instead of the ones that saturate HBM.
+int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off, hipStream_t stream,
+                      bool over_pcie = false);
 
 // ---- which engine ran -------------------------------------------------------------------------
 struct Stats {
@@ -64,8 +67,7 @@ extern Stats g_stats;
 bool gpu_required(); // MODGPU_REQUIRE_GPU=1 at load
 
 // ---- page-locked host memory ----------------------------------------------------------------
-// true if [p, p+n) lies inside one allocation of modgpu_host_alloc that is really pinned, or (for
-// large ranges only: the query costs microseconds) inside any other range HIP reports as pinned host memory.
+// true if [p, p+n) lies inside one allocation of modgpu_host_alloc that is really page-locked.
 bool host_range_pinned(const void *p, uint64_t n);
 
 // ---- host-buffer / file endpoints (host_stream.cpp) ---------------------------------------
@@ -82,5 +84,6 @@ struct Endpoint {
 int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t key, uint64_t stream_off, int device,
                 bool *touched);
 extern std::atomic<int> g_pinned_mode; // modgpu_debug_set_pinned_mode
+extern std::atomic<int> g_staged_mode; // modgpu_debug_set_staged_mode
 
 } // namespace modgpu

@@ -273,7 +273,8 @@ def test_config2_4gib_part_roundtrip(gpu, oracle, golden):
     dbuf.free()
 
 
-FUZZ_CASES = [("large", 1), ("large", 2), ("large", 3), ("large", 7), ("large", None), ("small", 1), ("small", 5), ("small", None)]
+FUZZ_CASES = [("large", 1), ("large", 2), ("large", 3), ("large", 7), ("large", None), ("small", 1), ("small", 5), ("small", None),
+              ("queue", 1), ("queue", 2), ("queue", 3), ("queue", 5), ("queue", 16), ("queue", None)]
 
 
 @pytest.mark.parametrize("case", range(len(FUZZ_CASES)))
@@ -288,9 +289,11 @@ def test_fuzz_forced_shapes(gpu, oracle, case):
     try:
         cap = (6 << 20) + 4096
         dbuf = gpu.DeviceBuffer(cap)
-        chunk = 131072 if shape == "large" else 4096
+        chunk = {"small": 4096, "large": 131072, "queue": 65536}[shape]
         sizes = [0, 1, 15, 16, 17, chunk - 16, chunk, chunk + 16, 2 * chunk, 2 * chunk + 5, 3 * chunk - 1, 5 * chunk + 123]
         sizes += [int(x) for x in rng.integers(0, 6 << 20, size=14)]
+        if shape == "queue":  # static prefix (3 chunks per workgroup) + ticketed chunks, many trips per workgroup
+            sizes += [3 * chunk, 4 * chunk, 4 * chunk + 1, 7 * chunk - 16, 40 * chunk + 77]
         for n in sizes:
             base = int(rng.integers(0, 4096)) if n % 3 else int(rng.integers(0, 300000))
             base = min(base, cap - n - 64)
@@ -303,7 +306,7 @@ def test_fuzz_forced_shapes(gpu, oracle, case):
             dbuf.sync()
             if n >= 16 and oracle.as_int32(key) % 0x7FFFFFFF:
                 info = gpu.last_launch()
-                assert info["variant"] == (1 if shape == "large" else 0) and info["chunk_bytes"] == chunk
+                assert info["variant"] == {"small": 0, "large": 1, "queue": 2}[shape] and info["chunk_bytes"] == chunk
                 assert grid is None or info["grid"] <= grid
             got = dbuf.download(n + 128, offset=lo)
             want = whole.copy()

@@ -324,3 +324,32 @@ def test_config5_eight_workers_aliased(host, oracle, tmp_path, header_cwd):
         o, s_ = by_name[f["name"]]
         assert f["size"] == s_ and np.array_equal(raw[f["offset"]:f["offset"] + s_], data[o:o + s_]), f["name"]
     b.close()
+
+
+def test_bench_two_ranks_rehearsal(host, tmp_path):
+    """The driver's N>1 launch line (torch.distributed.run, one rank per GPU) rehearsed with 2 ranks on this
+    box's one GPU: gloo for the barrier / MAX (RCCL wants one GPU per rank), both ranks on device 0.
+    Checks the contract's JSON line: whole-job value over both ranks, weak scaling, bit-exact check."""
+    import json
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--part-bytes", str(320 << 20), "--backend", "gloo", "--force-device", "0"],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3 and out["unit"] == "GB/s"
+    assert "config 3" in out["config"]["workload"] and out["config"]["bit_exact_check"].startswith("pass")
+    assert out["roofline"]["kernel"].startswith("modgpu_cycle_queue_kernel<4, 1024,") and out["roofline"]["grid"] == 256
+    assert "cpu_baseline" not in out  # rank 0 at N=1 only
+    assert abs(out["value"] - 2 * 3 * 2 * (320 << 20) / (out["ms_per_step"] * 3 * 1e-3) / 1e9) / out["value"] < 0.01

@@ -1,7 +1,10 @@
 """CPU, world_size 2 over gloo: the multi-GPU path is a partition with no data-path collective.
-The ranks here stand in for GPUs and use the oracle for the arithmetic (allowed in tests only);
-what is under test is the host logic bench.py and modgpu_cycle_parts_host share: round-robin
-part ownership, stream splitting by offset, and the MAX / SUM reductions of the bench contract."""
+The ranks here stand in for GPUs: each cycles the parts it owns with the PRODUCT's host loop
+(modgpu_cycle_scalar_host -- there is no GPU in this container) and the parent checks every part
+against the oracle.  Under test: round-robin part ownership, stream splitting by offset with
+stream_off, and the MAX / SUM reductions of the bench contract -- the host logic bench.py and
+modgpu_cycle_parts_host share.  (The N-worker GPU code itself runs in tests/test_gpu_parity.py::
+test_eight_workers_on_aliased_devices on the GPU box.)"""
 import os
 import socket
 
@@ -46,7 +49,8 @@ def _free_port():
 
 def _worker(rank, world, port, tmpdir):
     import torch.distributed as dist
-    from oracle import oracle as O
+    import modulate_amd as M
+    from oracle import oracle as O  # input generator only in the workers; the parent does the checking
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -56,13 +60,13 @@ def _worker(rank, world, port, tmpdir):
         sizes = [5000, 0, 70001, 4096, 33]
         for i in sharding.parts_for_rank(len(sizes), rank, world):
             part = O.splitmix_bytes(sizes[i], 100 + i)
-            O.cycle(part, O.KEY_PS4)
+            M.cycle_scalar_host(part, M.KEY_PS4)  # each part is its own Cycle from offset 0
             np.save(os.path.join(tmpdir, f"part{i}.npy"), part)
         # (2) one stream split across ranks by byte offset
         n = 200_003
         off, ln = sharding.split_stream(n, world)[rank]
         seg = O.splitmix_bytes(n, 9)[off:off + ln].copy()
-        O.cycle_at(seg, O.KEY_PS3, off)
+        M.cycle_scalar_host(seg, M.KEY_PS3, stream_off=off)
         np.save(os.path.join(tmpdir, f"seg{rank}.npy"), seg)
         # (3) bench contract reductions
         assert sharding.max_over_ranks(1.0 + rank) == float(world)
@@ -72,6 +76,7 @@ def _worker(rank, world, port, tmpdir):
         dist.destroy_process_group()
 
 
+@pytest.mark.skipif(os.environ.get("MODGPU_REQUIRE_GPU", "0") not in ("", "0"), reason="MODGPU_REQUIRE_GPU forbids the host loop the CPU ranks use")
 def test_world2_gloo(tmp_path, oracle):
     import torch.multiprocessing as mp
     world = 2

@@ -64,6 +64,21 @@ def main():
         hp[str(n)] = {"seconds_per_call": round(dt, 6), "GBps_payload": round(n / dt / 1e9, 3)}
         del buf
     res["host_path"] = hp
+    # the same on page-locked caller memory (modgpu_host_alloc: what CArk's part buffer is): no staging copy
+    hpp = {}
+    for n in (64 << 20, 411 << 20, 1 << 30, 1 << 32):
+        pb = M.PinnedBuffer(n + 64)
+        pb.array[:] = 7
+        view = pb.array[4:4 + n]
+        M.cycle_host(view, M.KEY_PS4)
+        reps = 5 if n <= (64 << 20) else 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            M.cycle_host(view, M.KEY_PS4)
+        dt = (time.perf_counter() - t0) / reps
+        hpp[str(n)] = {"seconds_per_call": round(dt, 6), "GBps_payload": round(n / dt / 1e9, 3)}
+        pb.free()
+    res["host_path_pinned"] = hpp
 
     # ---- config 1: 4 KiB framed blob, decrypt (plumbing)
     body = rng.integers(0, 256, size=4092, dtype=np.uint8)
@@ -84,6 +99,7 @@ def main():
     data = np.resize(tile, total)
     H.select_platform(True)
     H.set_flags(overwrite=True, ignore_new=False, pack_all=True, verbose=False)
+    H.set_fix_quirks(True)  # timing tool: SaveArk without the reference's "header must already exist in the cwd" check
     work = tempfile.mkdtemp(prefix="modcfg_", dir=a.tmp)
     try:
         first = os.path.join(work, "first") + "/"

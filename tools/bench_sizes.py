@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import modulate_amd as M  # noqa: E402
 
 cap = 1 << 30
+if len(sys.argv) > 1:  # force a launch shape: small | large | queue
+    M.debug_set_launch(sys.argv[1], 0)
 d = M.DeviceBuffer(cap + 64)
 d.upload(np.zeros(1 << 20, np.uint8))
 print(f"{'bytes':>12} {'us/launch':>10} {'GB/s r+w':>10}   (aligned base | base+4)")

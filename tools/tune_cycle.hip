@@ -24,13 +24,112 @@ struct Variant {
     std::vector<float> ms;
 };
 
-template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = 16, int SYNC = 0> void launch(const CycleArgs &a, uint32_t grid, hipStream_t st)
+template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = 16, int SYNC = 0, int TRACE = 0, int LDSW = 0> void launch(const CycleArgs &a, uint32_t grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((modgpu_cycle_kernel<U, BLOCK, ALG, PIPE, MODE, SAUX, SYNC>), dim3(grid), dim3(BLOCK), 0, st, a);
+    hipLaunchKernelGGL((modgpu_cycle_kernel<U, BLOCK, ALG, PIPE, MODE, SAUX, SYNC, TRACE, LDSW>), dim3(grid), dim3(BLOCK), 0, st, a);
+}
+
+template <int U, int BLOCK, int TRACE = 0> void launch_queue(const CycleArgs &a, uint32_t grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, 1, 16, TRACE>), dim3(grid), dim3(BLOCK), 0, st, a);
+}
+
+// `tune_cycle trace <bytes> [grid]`: where a launch's time goes.  Runs the shipped streaming shape with
+// TRACE=1 (lane 0 of each workgroup stamps wall_clock64 at start and after every trip's store burst) and
+// prints, relative to the earliest start: dispatch skew, the first trip (fill), steady-state trips, the
+// spread of finishing times (drain / imbalance), per XCD.
+static int trace_main(uint64_t n, uint32_t grid_cap, bool queue)
+{
+    uint8_t *buf;
+    uint64_t *trace, *h;
+    CHECK(hipMalloc(&buf, n + (1 << 20)));
+    CHECK(hipMemset(buf, 0x5A, n));
+    constexpr uint64_t chunk = 8ull * 1024 * 16;
+    uint32_t grid = (uint32_t)std::min<uint64_t>((n + chunk - 1) / chunk, grid_cap);
+    CHECK(hipMalloc(&trace, (size_t)grid * 32 * 8));
+    h = (uint64_t *)malloc((size_t)grid * 32 * 8);
+    hipStream_t st;
+    CHECK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    CycleArgs a{};
+    a.head_ptr = buf; a.body = buf; a.body_words = n / 16; a.tail_ptr = buf + n; a.trace = trace;
+    CHECK(hipMalloc(&a.queue, 64));
+    CHECK(hipMemset(a.queue, 0, 64));
+    printf("== %s schedule\n", queue ? "work-queue" : "static");
+    const uint32_t base0 = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
+    a.base_head = a.base_body = a.base_tail = base0;
+    a.stride_mul2 = 2u * lcg::powmod(lcg::A, ((uint64_t)grid * chunk) % lcg::PERIOD);
+    for (int rep = 0; rep < 4; ++rep) {
+        CHECK(hipMemsetAsync(trace, 0, (size_t)grid * 32 * 8, st));
+        // two untraced-equivalent launches in front so the traced one runs back to back like in the bench
+        if (queue) launch_queue<8, 1024, 1>(a, grid, st); else launch<8, 1024, 1, 2, MODE_FULL, 16, 3, 1>(a, grid, st);
+        CHECK(hipEventRecord(e0, st));
+        if (queue) launch_queue<8, 1024, 1>(a, grid, st); else launch<8, 1024, 1, 2, MODE_FULL, 16, 3, 1>(a, grid, st);
+        CHECK(hipEventRecord(e1, st));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        CHECK(hipMemcpy(h, trace, (size_t)grid * 32 * 8, hipMemcpyDeviceToHost));
+        uint64_t t0 = ~0ull;
+        for (uint32_t b = 0; b < grid; ++b) t0 = std::min(t0, h[b * 32]);
+        const uint64_t trips_max = (n / chunk + grid - 1) / grid;
+        std::vector<double> start, first, last, dur;
+        double xcd_end[8] = {}, xcd_n[8] = {};
+        std::vector<std::vector<double>> trip_dur(trips_max + 1);
+        for (uint32_t b = 0; b < grid; ++b) {
+            const uint64_t *r = h + b * 32;
+            uint32_t k = 1;
+            while (k < 31 && r[k]) ++k; // stamps 1..k-1 are trip ends
+            if (k < 2) continue;
+            start.push_back((r[0] - t0) * 0.01);
+            first.push_back((r[1] - r[0]) * 0.01);
+            last.push_back((r[k - 1] - t0) * 0.01);
+            for (uint32_t j = 2; j < k; ++j) trip_dur[std::min<uint64_t>(j, trips_max)].push_back((r[j] - r[j - 1]) * 0.01);
+            xcd_end[r[31] & 7] += (r[k - 1] - t0) * 0.01;
+            xcd_n[r[31] & 7] += 1;
+        }
+        auto stat = [](std::vector<double> v, const char *name) {
+            if (v.empty()) return;
+            std::sort(v.begin(), v.end());
+            double sum = 0;
+            for (double x : v) sum += x;
+            printf("  %-22s min %7.2f  p10 %7.2f  med %7.2f  p90 %7.2f  max %7.2f  mean %7.2f us  (n=%zu)\n", name, v.front(), v[v.size() / 10],
+                   v[v.size() / 2], v[v.size() * 9 / 10], v.back(), sum / v.size(), v.size());
+        };
+        if (rep == 0) continue; // warm
+        printf("bytes=%llu grid=%u trips/wg=%llu  launch (events) %.2f us -> %.1f GB/s r+w; traced stamps at 10 ns\n", (unsigned long long)n, grid,
+               (unsigned long long)trips_max, ms * 1e3, 2.0 * n / ms / 1e6);
+        stat(start, "wg start (skew)");
+        stat(first, "first trip (fill)");
+        for (uint64_t j = 2; j <= std::min<uint64_t>(trips_max, 4); ++j) {
+            char nm[32];
+            snprintf(nm, sizeof nm, "trip %llu%s", (unsigned long long)j, j == std::min<uint64_t>(trips_max, 4) && trips_max > 4 ? "+ (capped)" : "");
+            stat(trip_dur[j], nm);
+        }
+        if (trips_max > 4) {
+            std::vector<double> rest;
+            for (uint64_t j = 5; j <= trips_max; ++j) rest.insert(rest.end(), trip_dur[j].begin(), trip_dur[j].end());
+            stat(rest, "trips 5..last");
+        }
+        stat(last, "wg end");
+        {
+            std::vector<double> trips;
+            for (uint32_t b = 0; b < grid; ++b) { const uint64_t *r = h + b * 32; uint32_t k = 1; while (k < 31 && r[k]) ++k; trips.push_back(k - 1); }
+            stat(trips, "trips per wg (<=30 traced)");
+        }
+        printf("  mean wg end per XCD:");
+        for (int x = 0; x < 8; ++x) printf(" %7.2f", xcd_n[x] ? xcd_end[x] / xcd_n[x] : 0.0);
+        printf("\n");
+    }
+    return 0;
 }
 
 int main(int argc, char **argv)
 {
+    if (argc > 1 && std::string(argv[1]) == "trace")
+        return trace_main(argc > 2 ? strtoull(argv[2], nullptr, 0) : (1ull << 32), argc > 3 ? (uint32_t)atoi(argv[3]) : 256u, argc > 4 && atoi(argv[4]) != 0);
     uint64_t n = argc > 1 ? strtoull(argv[1], nullptr, 0) : (1ull << 32);
     int rounds = argc > 2 ? atoi(argv[2]) : 5;
     const bool cold = argc > 3 && atoi(argv[3]) != 0; // evict the buffer from the Infinity Cache before every launch
@@ -77,7 +176,25 @@ int main(int argc, char **argv)
     ADDY(4, 1024, 1, 2, MODE_FULL, 3, autogrid(65536, 256));
     ADDY(8, 1024, 1, 0, MODE_FULL, 0, autogrid(131072, 256));
     ADDY(8, 1024, 1, 2, MODE_FULL, 3, autogrid(131072, 256));
+    // the north_star's LDS write-combine stage, on the shipped shape: registers -> LDS -> registers -> store burst
+    vs.push_back({0, "full    U=8 B=1024 alg=1 pipe=2 sync=3 +LDS stage grid=  256", launch<8, 1024, 1, 2, MODE_FULL, 16, 3, 0, 1>, 131072, autogrid(131072, 256), {}});
+    vs.push_back({0, "full    U=4 B=1024 alg=1 pipe=2 sync=3 +LDS stage grid=  256", launch<4, 1024, 1, 2, MODE_FULL, 16, 3, 0, 1>, 65536, autogrid(65536, 256), {}});
+#define ADDQ(U, B, g)                                                                                      \
+    do {                                                                                                     \
+        char b_[128];                                                                                        \
+        snprintf(b_, sizeof b_, "queue   U=%d B=%4d work-queue schedule, %3d KiB chunks grid=%5u", U, B, U * B * 16 / 1024, (unsigned)autogrid((uint64_t)U * B * 16, g)); \
+        vs.push_back({0, b_, launch_queue<U, B>, (uint64_t)U * B * 16, autogrid((uint64_t)U * B * 16, g), {}}); \
+    } while (0)
+    ADDQ(8, 1024, 256);
+    ADDQ(4, 1024, 256);
+    ADDQ(2, 1024, 256);
+    ADDQ(8, 512, 512);
+    ADDQ(4, 512, 512);
+    ADDQ(8, 512, 256);
+    ADDQ(2, 512, 512);
     CycleArgs a{};
+    CHECK(hipMalloc(&a.queue, 64));
+    CHECK(hipMemset(a.queue, 0, 64));
     a.head_ptr = buf; a.head_n = 0; a.body = buf; a.body_words = n / 16; a.tail_ptr = buf + n; a.tail_n = 0; a.lead = 0;
     const uint32_t base0 = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
     a.base_head = a.base_body = a.base_tail = base0;
