@@ -25,7 +25,7 @@ int modgpu_time_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t st
 /* The launch the calling thread made last (any entry point), as the library planned it. */
 typedef struct modgpu_launch_info {
     const char *kernel;   /* the instantiation's name as rocprofv3 prints it, e.g.
-                             "modgpu_cycle_queue_kernel<8, 1024, 1, 16, 0>"; static storage      */
+                             "modgpu_cycle_queue_kernel<4, 1024, 1, 16, 0, 1>"; static storage   */
     int variant;          /* 0 = small shape, 1 = streaming shape (static chunk map), 2 = streaming shape fed by the work queue */
     uint32_t grid;        /* workgroups                                                           */
     uint32_t block;       /* threads per workgroup                                                */

@@ -49,12 +49,12 @@ template <int U, int BLOCK, int ALG, int SAUX> struct QueueShape {
     static constexpr uint32_t block = BLOCK;
     static void launch(const CycleArgs &a, uint32_t grid, hipStream_t stream)
     {
-        hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, ALG, SAUX, 0>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, ALG, SAUX, 0, 1>), dim3(grid), dim3(BLOCK), 0, stream, a);
     }
     static const char *name()
     {
         static char buf[96];
-        static const int n = std::snprintf(buf, sizeof buf, "modgpu_cycle_queue_kernel<%d, %d, %d, %d, 0>", U, BLOCK, ALG, SAUX);
+        static const int n = std::snprintf(buf, sizeof buf, "modgpu_cycle_queue_kernel<%d, %d, %d, %d, 0, 1>", U, BLOCK, ALG, SAUX);
         (void)n;
         return buf;
     }

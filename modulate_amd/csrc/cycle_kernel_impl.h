@@ -323,12 +323,16 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
 // value through one LDS word before the NEXT trip's second barrier, and every wave reads it after that
 // barrier.  a.queue[0] is the ticket counter, a.queue[1] counts workgroups that are done; the last one out
 // zeroes both, so the pair is clean for the next launch without a memset.
-template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int TRACE = 0>
+// DEPTH = chunks of loads a workgroup keeps in flight ahead of the one it computes (1 = ping-pong as above)
+template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int TRACE = 0, int DEPTH = 1>
 __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
 {
     static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
+    static_assert(DEPTH >= 1 && DEPTH <= 3, "1..3 chunks of loads in flight");
     constexpr uint32_t CHUNK = (uint32_t)U * BLOCK * lcg::WORD;
     constexpr uint32_t SUB = BLOCK * lcg::WORD;
+    constexpr int NB = DEPTH + 1;     // register buffers: one being computed, DEPTH being loaded
+    constexpr int PREFIX = DEPTH + 2; // static chunks per workgroup: a ticket fetched in trip j feeds trip j + PREFIX
     const uint32_t tid = threadIdx.x;
     const uint32_t blk = blockIdx.x;
     const uint32_t G = gridDim.x;
@@ -417,31 +421,38 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
     auto take_published = [&]() { // every lane, after the trip's second barrier
         uint32_t t;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(q_next_lds) : "memory");
-        return first + 3u * G + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        return first + (uint32_t)PREFIX * G + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     };
 
-    uint32_t c0 = first + blk, c1 = c0 + G, c2 = c1 + G; // static prefix; tickets continue from first + 3G
-    if (c0 < n_chunks) {
-        u32x4 d0[U], d1[U];
-        load(d0, c0);
-        bool publish = false; // the first trip has no ticket to publish yet: c2 is static
-        while (true) {
-            __builtin_amdgcn_s_barrier();
-            load(d1, c1);
-            __builtin_amdgcn_sched_barrier(0);
-            process_store(d0, c0, publish);
-            c0 = c1;
-            c1 = c2;
-            if (publish) c1 = take_published();
-            publish = true;
-            if (c0 >= n_chunks) break;
-            __builtin_amdgcn_s_barrier();
-            load(d0, c1);
-            __builtin_amdgcn_sched_barrier(0);
-            process_store(d1, c0, true);
-            c0 = c1;
-            c1 = take_published();
-            if (c0 >= n_chunks) break;
+    // A workgroup's chunk sequence: positions 0 .. PREFIX-1 are static (b, b+G, ...), position j + PREFIX is the
+    // ticket fetched in trip j.  cq[] holds positions k .. k+DEPTH at the start of trip k: cq[0] is computed,
+    // cq[DEPTH] is loaded now, the ones between are already in flight.
+    uint32_t cq[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) cq[i] = first + blk + (uint32_t)i * G;
+    const uint32_t last_static = first + blk + (uint32_t)NB * G; // position PREFIX-1, enters cq after trip 0
+    if (cq[0] < n_chunks) {
+        u32x4 d[NB][U];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) load(d[i], cq[i]);
+        bool publish = false; // the first trip has no ticket to publish yet
+        bool finished = false;
+        while (!finished) {
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                __builtin_amdgcn_s_barrier();
+                load(d[(p + DEPTH) % NB], cq[DEPTH]);
+                __builtin_amdgcn_sched_barrier(0);
+                process_store(d[p], cq[0], publish);
+#pragma unroll
+                for (int i = 0; i < DEPTH; ++i) cq[i] = cq[i + 1];
+                cq[DEPTH] = publish ? take_published() : last_static;
+                publish = true;
+                if (cq[0] >= n_chunks) {
+                    finished = true;
+                    break;
+                }
+            }
         }
     }
     // leave: this workgroup's ticket atomics have all returned; the last workgroup out resets the pair

@@ -151,7 +151,7 @@ uint32_t large_grid()
 constexpr uint32_t kQueueRing = 256;
 struct QueueRing {
     std::mutex mu;
-    uint32_t *base = nullptr; // kQueueRing lines of 16 words
+    std::atomic<uint32_t *> base{nullptr}; // kQueueRing lines of 16 words
     std::atomic<uint32_t> next{0};
 };
 QueueRing g_queue_ring[kMaxDevices];
@@ -163,23 +163,25 @@ uint32_t *queue_pair(hipStream_t stream)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
     QueueRing &r = g_queue_ring[dev];
-    if (!r.base) {
+    uint32_t *base = r.base.load(std::memory_order_acquire);
+    if (!base) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
             (void)hipGetLastError();
             return nullptr;
         }
         std::lock_guard<std::mutex> lock(r.mu);
-        if (!r.base) {
+        base = r.base.load(std::memory_order_acquire);
+        if (!base) {
             uint32_t *p = nullptr;
             if (hipMalloc(reinterpret_cast<void **>(&p), kQueueRing * 64) != hipSuccess || hipMemset(p, 0, kQueueRing * 64) != hipSuccess) {
                 (void)hipGetLastError();
                 return nullptr;
             }
-            r.base = p;
+            r.base.store(base = p, std::memory_order_release);
         }
     }
-    return r.base + (size_t)(r.next.fetch_add(1, std::memory_order_relaxed) % kQueueRing) * 16;
+    return base + (size_t)(r.next.fetch_add(1, std::memory_order_relaxed) % kQueueRing) * 16;
 }
 
 constexpr uint32_t kSmallGridMax = 16384u;   // 4 KiB chunks: grid * 1 tile <= 65536
@@ -223,7 +225,10 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
     uint64_t chunk = modgpu_variant_chunk_bytes(p.variant);
     if (p.variant == CYCLE_QUEUE) { // needs a clean ticket pair and chunk indices that fit its 3-byte jump tables
         a.queue = (body_bytes + chunk) / chunk + 4ull * 2048 < (1ull << 24) ? queue_pair(stream) : nullptr;
-        if (!a.queue) p.variant = CYCLE_LARGE;
+        if (!a.queue) {
+            p.variant = CYCLE_LARGE;
+            chunk = modgpu_variant_chunk_bytes(p.variant);
+        }
     }
     // chunks sit on absolute chunk-aligned addresses: the first starts `lead` bytes before the body,
     // and the kernel counts positions from there, so its base state is stepped back by a^(-lead)

@@ -43,7 +43,7 @@ def main():
         w.writerows(rows)
     for r in rows[:5]:
         print(f"{r['calls']:6d} x avg {r['avg_ns']/1e3:10.1f} us  {r['kernel'][:90]}")
-    cyc = [r for r in rows if "modgpu_cycle_kernel" in r["kernel"]]
+    cyc = [r for r in rows if "modgpu_cycle_" in r["kernel"]]  # rows are sorted by total time: [0] is the dominant kernel
     if cyc:
         out["cycle_kernel"] = cyc[0]["kernel"]
         out["avg_launch_ns_traced"] = cyc[0]["avg_ns"]
@@ -52,7 +52,7 @@ def main():
         vals = defaultdict(float)
         for f in find(os.path.join(root, dirname), "*counter_collection.csv"):
             for r in csv.DictReader(open(f)):
-                if "modgpu_cycle_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name:
+                if "modgpu_cycle_" in r["Kernel_Name"] and r["Counter_Name"] == name:
                     vals[(r["Dispatch_Id"])] += float(r["Counter_Value"])
         return list(vals.values())
     fetch = counter("pmc_fetch", "FETCH_SIZE")

@@ -29,9 +29,9 @@ template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = 16, int SYNC
     hipLaunchKernelGGL((modgpu_cycle_kernel<U, BLOCK, ALG, PIPE, MODE, SAUX, SYNC, TRACE, LDSW>), dim3(grid), dim3(BLOCK), 0, st, a);
 }
 
-template <int U, int BLOCK, int TRACE = 0> void launch_queue(const CycleArgs &a, uint32_t grid, hipStream_t st)
+template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1> void launch_queue(const CycleArgs &a, uint32_t grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, 1, 16, TRACE>), dim3(grid), dim3(BLOCK), 0, st, a);
+    hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, 1, 16, TRACE, DEPTH>), dim3(grid), dim3(BLOCK), 0, st, a);
 }
 
 // `tune_cycle trace <bytes> [grid]`: where a launch's time goes.  Runs the shipped streaming shape with
@@ -185,13 +185,18 @@ int main(int argc, char **argv)
         snprintf(b_, sizeof b_, "queue   U=%d B=%4d work-queue schedule, %3d KiB chunks grid=%5u", U, B, U * B * 16 / 1024, (unsigned)autogrid((uint64_t)U * B * 16, g)); \
         vs.push_back({0, b_, launch_queue<U, B>, (uint64_t)U * B * 16, autogrid((uint64_t)U * B * 16, g), {}}); \
     } while (0)
+#define ADDQD(U, B, D, g)                                                                                  \
+    do {                                                                                                     \
+        char b_[128];                                                                                        \
+        snprintf(b_, sizeof b_, "queue   U=%d B=%4d depth=%d work-queue, %3d KiB chunks grid=%5u", U, B, D, U * B * 16 / 1024, (unsigned)autogrid((uint64_t)U * B * 16, g)); \
+        vs.push_back({0, b_, launch_queue<U, B, 0, D>, (uint64_t)U * B * 16, autogrid((uint64_t)U * B * 16, g), {}}); \
+    } while (0)
     ADDQ(8, 1024, 256);
     ADDQ(4, 1024, 256);
-    ADDQ(2, 1024, 256);
-    ADDQ(8, 512, 512);
-    ADDQ(4, 512, 512);
     ADDQ(8, 512, 256);
-    ADDQ(2, 512, 512);
+    ADDQD(4, 1024, 2, 256);
+    ADDQD(4, 1024, 3, 256);
+    ADDQD(8, 512, 2, 256);
     CycleArgs a{};
     CHECK(hipMalloc(&a.queue, 64));
     CHECK(hipMemset(a.queue, 0, 64));
