@@ -25,7 +25,7 @@ int modgpu_time_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t st
 /* The launch the calling thread made last (any entry point), as the library planned it. */
 typedef struct modgpu_launch_info {
     const char *kernel;   /* the instantiation's name as rocprofv3 prints it, e.g.
-                             "modgpu_cycle_queue_kernel<4, 1024, 1, 16, 0, 1>"; static storage   */
+                             "modgpu_cycle_queue_kernel<4, 1024, 1, 18, 0, 1, 0, 2, 1, 1>"; static storage */
     int variant;          /* 0 = small shape, 1 = streaming shape (static chunk map), 2 = streaming shape fed by the work queue */
     uint32_t grid;        /* workgroups                                                           */
     uint32_t block;       /* threads per workgroup                                                */
@@ -45,8 +45,8 @@ void modgpu_debug_set_launch(int variant, uint32_t grid_cap);
 void modgpu_debug_set_pinned_mode(int mode);
 
 /* How a staged chunk (pageable memory or a file, copied into a pinned slot) is cycled: 0 = library
- * default, 1 = H2D -> kernel in HBM -> D2H, 2 = the kernel works on the pinned slot across PCIe (no DMA
- * submissions, no device slot).  Same bytes; tools/sweep_pinned.py times them. */
+ * default (= 2), 1 = H2D -> kernel in HBM -> D2H, 2 = the kernel works on the pinned slot across PCIe
+ * (no DMA submissions, no device slot).  Same bytes; tools/sweep_pinned.py times them. */
 void modgpu_debug_set_staged_mode(int mode);
 
 /* Identity of the device code this library carries: hex SHA-256 over the kernel sources it was

@@ -43,18 +43,21 @@ template <int U, int BLOCK, int ALG, int PIPE, int SAUX, int SYNC> struct Shape 
         return buf;
     }
 };
-// the same streaming shape fed from a ticket counter instead of the static chunk map
+// the streaming shape fed from a ticket counter instead of the static chunk map
 template <int U, int BLOCK, int ALG, int SAUX> struct QueueShape {
     static constexpr uint32_t chunk = (uint32_t)U * BLOCK * lcg::WORD;
     static constexpr uint32_t block = BLOCK;
+    // product settings of the tuning-only template arguments: TRACE 0, DEPTH 1, MODE_FULL, nt loads, both
+    // workgroup barriers (B1 in front of the load burst, B2 in front of the store burst)
     static void launch(const CycleArgs &a, uint32_t grid, hipStream_t stream)
     {
-        hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, ALG, SAUX, 0, 1>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, ALG, SAUX, 0, 1, MODE_FULL, AUX_NT, 1, 1>), dim3(grid), dim3(BLOCK), 0, stream, a);
     }
     static const char *name()
     {
-        static char buf[96];
-        static const int n = std::snprintf(buf, sizeof buf, "modgpu_cycle_queue_kernel<%d, %d, %d, %d, 0, 1>", U, BLOCK, ALG, SAUX);
+        static char buf[128];
+        static const int n = std::snprintf(buf, sizeof buf, "modgpu_cycle_queue_kernel<%d, %d, %d, %d, 0, 1, %d, %d, 1, 1>", U, BLOCK, ALG, SAUX,
+                                           (int)MODE_FULL, (int)AUX_NT);
         (void)n;
         return buf;
     }
@@ -63,9 +66,11 @@ template <int U, int BLOCK, int ALG, int SAUX> struct QueueShape {
 using Small = Shape<1, 256, 1, 0, AUX_SC1, 0>;
 // U=8 words x 1024 threads, SDWA keystream, pipelined + loads-first, sc1 stores, workgroup-synchronous bursts
 using Large = Shape<8, 1024, 1, 2, AUX_SC1, 3>;
-// 64 KiB chunks: measured best under the queue (profiles/r02_tune_cycle_queue_shapes.txt): 128 KiB balances
-// coarser, 32 KiB and below saturate the ticket counter (~80 tickets/us chip-wide)
-using Queue = QueueShape<4, 1024, 1, AUX_SC1>;
+// 1024 threads x 4 words = 64 KiB chunks: measured best under the queue (profiles/r02_tune_cycle_queue_shapes.txt,
+// every row validated): 128 KiB chunks balance coarser, 32 KiB and below saturate the ticket counter (~80 tickets/us
+// chip-wide), 512-thread workgroups and a second chunk of loads in flight lose 1 %; stores sc1+nt gain 0.5-1.8 %
+// over sc1 alone at every size
+using Queue = QueueShape<4, 1024, 1, AUX_SC1 | AUX_NT>;
 } // namespace
 
 uint32_t modgpu_variant_chunk_bytes(int variant)

@@ -324,7 +324,13 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
 // barrier.  a.queue[0] is the ticket counter, a.queue[1] counts workgroups that are done; the last one out
 // zeroes both, so the pair is clean for the next launch without a memset.
 // DEPTH = chunks of loads a workgroup keeps in flight ahead of the one it computes (1 = ping-pong as above)
-template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int TRACE = 0, int DEPTH = 1>
+// MODE  = MODE_FULL in the product; MODE_COPY (tools/tune_cycle) is the same loop without the keystream: the
+//         memory system's ceiling for this access pattern
+// LAUX  = cache-policy bits of the loads (AUX_NT in the product); B1 = 0 drops the barrier in front of each trip's
+//         load burst (tools/tune_cycle only)
+// B2    = 0 (tools/tune_cycle, TIMING ONLY -- results are wrong): drops the second barrier too, so the ticket
+//         hand-off races; answers what a barrier-free workgroup would gain
+template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int LAUX = AUX_NT, int B1 = 1, int B2 = 1>
 __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
 {
     static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
@@ -336,8 +342,12 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
     const uint32_t tid = threadIdx.x;
     const uint32_t blk = blockIdx.x;
     const uint32_t G = gridDim.x;
-    __shared__ uint32_t q_next;
-    [[maybe_unused]] uint32_t trip = 0;
+    // Two LDS words, used alternately: a trip's ticket is written before that trip's barrier and read after it, and
+    // the same word is written again two trips later -- i.e. behind the NEXT trip's barrier, which no wave can reach
+    // before it has done this trip's read.  (With a single word a wave held up between the barrier and its read
+    // could in principle be overtaken by lane 0's next write, there being no barrier in front of the loads.)
+    __shared__ uint32_t q_next[2];
+    uint32_t trip = 0;
     [[maybe_unused]] auto stamp = [&](uint32_t slot) {
         if constexpr (TRACE != 0) {
             if (tid == 0 && slot < 31) a.trace[blk * 32 + slot] = wall_clock64();
@@ -390,7 +400,7 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
     auto load = [&](u32x4(&d)[U], uint32_t c) {
         auto r = rsrc_at(c);
 #pragma unroll
-        for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, AUX_NT);
+        for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, LAUX);
     };
     // Lane 0's ticket traffic.  The returning atomic is a plain compiler-visible atomic, so the compiler counts it
     // in its own s_waitcnt vmcnt(N) bookkeeping and waits for the value only where it is published, a trip
@@ -400,27 +410,33 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
     // The LDS word is accessed with ds_write / ds_read in assembly: a volatile C++ access to a __shared__
     // variable becomes a FLAT access, which waits on vmcnt as well as lgkmcnt.
     uint32_t pending = 0; // lane 0: the ticket in flight
-    const uint32_t q_next_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&q_next;
+    const uint32_t q_next_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&q_next[0];
     const uint32_t one = 1u;
     // one trip: chunk c's words are in d; compute, publish last trip's ticket, barrier, fetch a ticket, store burst
     auto process_store = [&](u32x4(&d)[U], uint32_t c, bool publish) {
         auto r = rsrc_at(c);
-        uint32_t s[U];
-        states(c, s);
+        if constexpr (MODE == MODE_COPY) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) d[u] = cycle_word<ALG>(d[u], s[u]);
+            for (int u = 0; u < U; ++u) d[u] = ~d[u];
+        } else {
+            uint32_t s[U];
+            states(c, s);
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = cycle_word<ALG>(d[u], s[u]);
+        }
         if (publish && tid == 0) // (the LDS write has landed before the barrier releases the readers)
-            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(q_next_lds), "v"(pending) : "memory");
+            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(q_next_lds + 4u * (trip & 1u)), "v"(pending) : "memory");
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (B2 != 0) __builtin_amdgcn_s_barrier();
         if (tid == 0) pending = __hip_atomic_fetch_add(a.queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
-        stamp(++trip);
+        ++trip;
+        stamp(trip);
     };
-    auto take_published = [&]() { // every lane, after the trip's second barrier
+    auto take_published = [&]() { // every lane, after the trip's barrier (trip already counted: the word is (trip-1)&1)
         uint32_t t;
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(q_next_lds) : "memory");
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(q_next_lds + 4u * ((trip - 1u) & 1u)) : "memory");
         return first + (uint32_t)PREFIX * G + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     };
 
@@ -440,7 +456,7 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
         while (!finished) {
 #pragma unroll
             for (int p = 0; p < NB; ++p) {
-                __builtin_amdgcn_s_barrier();
+                if constexpr (B1 != 0) __builtin_amdgcn_s_barrier();
                 load(d[(p + DEPTH) % NB], cq[DEPTH]);
                 __builtin_amdgcn_sched_barrier(0);
                 process_store(d[p], cq[0], publish);

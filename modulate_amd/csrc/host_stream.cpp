@@ -11,9 +11,12 @@
 //                     bytes, slower at 26-29 GB/s and kept selectable: chunked H2D -> kernel in HBM -> D2H
 //                     straight from / to the pages through a ring of device slots.)  When only one side of a
 //                     file stream is pinned memory, that side is DMA'd directly and the file side staged.
-//   pageable, large   memcpy -> pinned slot -> H2D -> kernel -> D2H -> pinned slot -> memcpy, spread
-//                     over kPipes independent pipelines (host thread + two slots each): one thread
-//                     copies pageable<->pinned at 22 GB/s, four at 73 (profiles/r01_ubench_hostpath.txt).
+//   pageable, large   memcpy -> pinned slot -> kernel over PCIe on the slot -> memcpy back, spread over kPipes
+//                     independent pipelines (host thread + two slots each, double-buffered): one thread
+//                     copies pageable<->pinned at 22 GB/s, eight at 113 (profiles/r01_ubench_hostpath.txt),
+//                     so the copies hide under the link.  41-43 GB/s at 1-4 GiB with 8 pipelines x 8 MiB
+//                     slots, against 27-30 for the r01 form of this route (memcpy -> H2D DMA -> kernel in HBM ->
+//                     D2H DMA -> memcpy, kept selectable; profiles/r02_sweep_staged_routes.txt).
 //                     A file endpoint replaces its memcpy by pread / pwrite on the pinned slot.
 //   small (<= 1 MiB)  what the reference's three call sites pass (headers): no DMA submissions at
 //                     all, the kernel reads and writes pinned memory across PCIe itself.
@@ -54,8 +57,8 @@ int env_int(const char *name, int dflt, int lo, int hi)
     int x = std::atoi(v);
     return x < lo ? lo : (x > hi ? hi : x);
 }
-const int kPipes = env_int("MODGPU_HOST_PIPES", 4, 1, kMaxPipes);
-const uint64_t kChunk = (uint64_t)env_int("MODGPU_HOST_CHUNK_MB", 16, 1, 256) << 20;
+const int kPipes = env_int("MODGPU_HOST_PIPES", 8, 1, kMaxPipes);
+const uint64_t kChunk = (uint64_t)env_int("MODGPU_HOST_CHUNK_MB", 8, 1, 256) << 20;
 const uint64_t kZeroCopyMax = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_ZEROCOPY_KB", 1024, 0, 1 << 20) << 10, kChunk);
 const int kRing = env_int("MODGPU_HOST_RING", 4, 2, 4);
 
@@ -258,14 +261,14 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
         return MODGPU_OK;
     }
 
-    // slot size: the whole buffer if it is small, else ~n/16 between 4 MiB and the cap (measured:
-    // 4 MiB slots are best at 64 MiB, 16 MiB slots from 1 GiB up; profiles/r01_sweep_hostpath.txt)
+    // slot size: the whole buffer if it is small, else ~n/16 between 4 MiB and the cap (8 MiB by default:
+    // profiles/r02_sweep_staged_routes.txt)
     uint64_t chunk = n <= (4ull << 20) ? std::max<uint64_t>(n, 1ull << 20)
                                        : std::min<uint64_t>(kChunk, std::max<uint64_t>(4ull << 20, ((n >> 4) + 0xFFFFF) & ~0xFFFFFull));
     chunk = std::min<uint64_t>(chunk, kChunk);
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
     Job job{src, dst, n, chunk, key, stream_off};
-    job.slot_kernel = !src_direct && !dst_direct && g_staged_mode.load(std::memory_order_relaxed) == 2;
+    job.slot_kernel = !src_direct && !dst_direct && g_staged_mode.load(std::memory_order_relaxed) != 1;
     int pipes, ring;
     if (all_direct && src.mem && dst.mem) { // no host work at all: one thread keeps a ring of slots busy
         pipes = 1;

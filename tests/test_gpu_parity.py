@@ -140,13 +140,27 @@ def test_split_stream_equals_one_call(gpu, oracle):
 
 def test_host_path_chunk_boundaries(gpu, oracle):
     """Host API across its internal staging chunks, slot rings and worker pipelines at the default
-    tunables (4 pipelines x 2 slots, slots of n/16 clamped to 4..16 MiB); test_host_path_tunables runs the
-    same sizes off-default."""
+    tunables (8 pipelines x 2 slots, slots of n/16 clamped to 4..8 MiB, kernel over PCIe on the slot);
+    test_host_path_tunables runs the same sizes off-default, test_staged_dma_route the DMA form of the route."""
     for n in HOST_PATH_SIZES:
         pt = oracle.splitmix_bytes(n, n)
         ct = gpu.cycle_host(pt.copy(), 0xC64EED30)
         assert np.array_equal(ct, oracle.cycle(pt.copy(), 0xC64EED30)), n
         assert np.array_equal(gpu.cycle_host(ct, 0xC64EED30), pt)
+
+
+def test_staged_dma_route(gpu, oracle):
+    """The other form of the staged route (H2D DMA -> kernel in HBM -> D2H DMA per slot), same bytes."""
+    gpu.debug_set_staged_mode(1)
+    try:
+        for n in (HOST_PATH_SIZES[0], HOST_PATH_SIZES[3]):
+            pt = oracle.splitmix_bytes(n, n)
+            ct = gpu.cycle_host(pt.copy(), 0x90CFC0AB, stream_off=77)
+            want = pt.copy()
+            oracle.cycle_at(want, 0x90CFC0AB, 77)
+            assert np.array_equal(ct, want), n
+    finally:
+        gpu.debug_set_staged_mode(0)
 
 
 def test_parts_sharding_host(gpu, oracle):
@@ -393,8 +407,8 @@ assert st["scalar_calls"] == 0 and st["gpu_calls"] == 4 * len(sizes), st
 print("TUNABLES_OK", st["staged_bytes"], st["direct_bytes"])
 """
 
-TUNABLES = [{"MODGPU_HOST_PIPES": "1"}, {"MODGPU_HOST_PIPES": "2"}, {"MODGPU_HOST_PIPES": "8"}, {"MODGPU_HOST_PIPES": "16"},
-            {"MODGPU_HOST_CHUNK_MB": "1"}, {"MODGPU_HOST_CHUNK_MB": "4"}, {"MODGPU_HOST_CHUNK_MB": "64"},
+TUNABLES = [{"MODGPU_HOST_PIPES": "1"}, {"MODGPU_HOST_PIPES": "2"}, {"MODGPU_HOST_PIPES": "4"}, {"MODGPU_HOST_PIPES": "16"},
+            {"MODGPU_HOST_CHUNK_MB": "1"}, {"MODGPU_HOST_CHUNK_MB": "4"}, {"MODGPU_HOST_CHUNK_MB": "16"}, {"MODGPU_HOST_CHUNK_MB": "64"},
             {"MODGPU_HOST_ZEROCOPY_KB": "0"}, {"MODGPU_HOST_RING": "2"},
             # ADVICE r1: a zero-copy limit above the slot size used to overrun the pinned staging buffer
             {"MODGPU_HOST_CHUNK_MB": "1", "MODGPU_HOST_ZEROCOPY_KB": "2048"},
@@ -406,7 +420,7 @@ def test_host_path_tunables(gpu, env):
     """MODGPU_HOST_PIPES / _CHUNK_MB / _ZEROCOPY_KB / _RING off their defaults, on the chunk-boundary sizes,
     pageable and pinned caller memory, encrypt + decrypt, whole-buffer compare against the oracle."""
     sizes = [4097, (1 << 20) + 1, (2 << 20) - 1] + list(HOST_PATH_SIZES[:4])
-    if env.get("MODGPU_HOST_CHUNK_MB") == "64" or env.get("MODGPU_HOST_PIPES") in ("8", "16"):
+    if env.get("MODGPU_HOST_CHUNK_MB") == "64" or env.get("MODGPU_HOST_PIPES") in ("4", "16"):
         sizes.append(HOST_PATH_SIZES[4])
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-c", _TUNABLE_CHILD % (ROOT, sizes)], capture_output=True, text=True, env=e, timeout=900)

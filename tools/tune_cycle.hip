@@ -15,6 +15,17 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
+// Every variant is launched an even number of times, and the cipher is an involution: if a variant processed
+// every chunk exactly once per launch the buffer is back to its fill pattern afterwards.  A variant whose
+// schedule drops or repeats chunks (a racy hand-off, say) looks FAST precisely because it skips work, so its
+// row is only printed as valid when this count is zero.
+__global__ void count_mismatches(const uint32_t *p, uint64_t n_words, uint32_t want, unsigned long long *out)
+{
+    unsigned long long bad = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) bad += p[i] != want;
+    if (bad) atomicAdd(out, bad);
+}
+
 struct Variant {
     uint32_t base_off = 0;
     std::string name;
@@ -22,6 +33,7 @@ struct Variant {
     uint64_t chunk;
     uint32_t grid;
     std::vector<float> ms;
+    unsigned long long bad = 0;
 };
 
 template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = 16, int SYNC = 0, int TRACE = 0, int LDSW = 0> void launch(const CycleArgs &a, uint32_t grid, hipStream_t st)
@@ -29,9 +41,9 @@ template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = 16, int SYNC
     hipLaunchKernelGGL((modgpu_cycle_kernel<U, BLOCK, ALG, PIPE, MODE, SAUX, SYNC, TRACE, LDSW>), dim3(grid), dim3(BLOCK), 0, st, a);
 }
 
-template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1> void launch_queue(const CycleArgs &a, uint32_t grid, hipStream_t st)
+template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int SAUX = 16, int LAUX = 2, int B1 = 1, int B2 = 1> void launch_queue(const CycleArgs &a, uint32_t grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, 1, 16, TRACE, DEPTH>), dim3(grid), dim3(BLOCK), 0, st, a);
+    hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, 1, SAUX, TRACE, DEPTH, MODE, LAUX, B1, B2>), dim3(grid), dim3(BLOCK), 0, st, a);
 }
 
 // `tune_cycle trace <bytes> [grid]`: where a launch's time goes.  Runs the shipped streaming shape with
@@ -179,24 +191,28 @@ int main(int argc, char **argv)
     // the north_star's LDS write-combine stage, on the shipped shape: registers -> LDS -> registers -> store burst
     vs.push_back({0, "full    U=8 B=1024 alg=1 pipe=2 sync=3 +LDS stage grid=  256", launch<8, 1024, 1, 2, MODE_FULL, 16, 3, 0, 1>, 131072, autogrid(131072, 256), {}});
     vs.push_back({0, "full    U=4 B=1024 alg=1 pipe=2 sync=3 +LDS stage grid=  256", launch<4, 1024, 1, 2, MODE_FULL, 16, 3, 0, 1>, 65536, autogrid(65536, 256), {}});
-#define ADDQ(U, B, g)                                                                                      \
+// queue kernel variants: U, BLOCK, DEPTH, store policy, load policy, barrier before loads (B1), grid cap
+#define ADDQX(U, B, D, SA, LA, B1, g)                                                                       \
     do {                                                                                                     \
-        char b_[128];                                                                                        \
-        snprintf(b_, sizeof b_, "queue   U=%d B=%4d work-queue schedule, %3d KiB chunks grid=%5u", U, B, U * B * 16 / 1024, (unsigned)autogrid((uint64_t)U * B * 16, g)); \
-        vs.push_back({0, b_, launch_queue<U, B>, (uint64_t)U * B * 16, autogrid((uint64_t)U * B * 16, g), {}}); \
+        char b_[160];                                                                                        \
+        snprintf(b_, sizeof b_, "queue   U=%2d B=%4d depth=%d st=%2d ld=%2d b1=%d %3d KiB chunks grid=%4u", U, B, D, SA, LA, B1, U * B * 16 / 1024, (unsigned)autogrid((uint64_t)U * B * 16, g)); \
+        vs.push_back({0, b_, launch_queue<U, B, 0, D, MODE_FULL, SA, LA, B1>, (uint64_t)U * B * 16, autogrid((uint64_t)U * B * 16, g), {}}); \
     } while (0)
-#define ADDQD(U, B, D, g)                                                                                  \
-    do {                                                                                                     \
-        char b_[128];                                                                                        \
-        snprintf(b_, sizeof b_, "queue   U=%d B=%4d depth=%d work-queue, %3d KiB chunks grid=%5u", U, B, D, U * B * 16 / 1024, (unsigned)autogrid((uint64_t)U * B * 16, g)); \
-        vs.push_back({0, b_, launch_queue<U, B, 0, D>, (uint64_t)U * B * 16, autogrid((uint64_t)U * B * 16, g), {}}); \
-    } while (0)
-    ADDQ(8, 1024, 256);
-    ADDQ(4, 1024, 256);
-    ADDQ(8, 512, 256);
-    ADDQD(4, 1024, 2, 256);
-    ADDQD(4, 1024, 3, 256);
-    ADDQD(8, 512, 2, 256);
+    ADDQX(4, 1024, 1, 16, 2, 1, 256); // shipped
+    ADDQX(4, 1024, 1, 16, 2, 0, 256);
+    ADDQX(8, 1024, 1, 16, 2, 1, 256);
+    ADDQX(8, 512, 1, 16, 2, 1, 256);
+    ADDQX(8, 512, 1, 16, 2, 0, 256);
+    ADDQX(8, 512, 1, 16, 2, 1, 512);
+    ADDQX(4, 1024, 2, 16, 2, 1, 256);
+    ADDQX(4, 1024, 1, 18, 2, 1, 256);
+    ADDQX(4, 1024, 1, 2, 2, 1, 256);
+    ADDQX(4, 1024, 1, 0, 2, 1, 256);
+    ADDQX(4, 1024, 1, 16, 0, 1, 256);
+    ADDQX(4, 1024, 1, 16, 18, 1, 256);
+    ADDQX(2, 1024, 1, 16, 2, 1, 256);
+    vs.push_back({0, "queue   U= 4 B=1024 COPY-ONLY (no keystream) b1=1 64 KiB chunks grid= 256", launch_queue<4, 1024, 0, 1, MODE_COPY, 16, 2, 1>, 65536, autogrid(65536, 256), {}});
+    vs.push_back({0, "queue   U= 4 B=1024 NO barriers: racy ticket hand-off    64 KiB grid= 256", launch_queue<4, 1024, 0, 1, MODE_FULL, 16, 2, 0, 0>, 65536, autogrid(65536, 256), {}});
     CycleArgs a{};
     CHECK(hipMalloc(&a.queue, 64));
     CHECK(hipMemset(a.queue, 0, 64));
@@ -221,12 +237,29 @@ int main(int argc, char **argv)
         }
     }
     CHECK(hipGetLastError());
+    // validity pass: two launches of each variant on the freshly filled buffer must give the fill pattern back
+    unsigned long long *d_bad;
+    CHECK(hipMalloc(&d_bad, 8));
+    for (auto &v : vs) {
+        if (v.name.find("compute") == 0) continue; // the compute-only ablation never stores
+        CHECK(hipMemsetAsync(buf, 0x5A, n, st));
+        CHECK(hipMemsetAsync(d_bad, 0, 8, st));
+        a.body = buf + v.base_off;
+        a.lead = (uint32_t)((uintptr_t)a.body & (v.chunk - 1));
+        a.base_body = lcg::mulmod(base0, lcg::powmod(lcg::A, lcg::PERIOD - a.lead));
+        a.stride_mul2 = 2u * lcg::powmod(lcg::A, ((uint64_t)v.grid * v.chunk) % lcg::PERIOD);
+        v.launch(a, v.grid, st);
+        v.launch(a, v.grid, st);
+        hipLaunchKernelGGL(count_mismatches, dim3(2048), dim3(256), 0, st, (const uint32_t *)buf, n / 4, 0x5A5A5A5Au, d_bad);
+        CHECK(hipMemcpyAsync(&v.bad, d_bad, 8, hipMemcpyDeviceToHost, st));
+        CHECK(hipStreamSynchronize(st));
+    }
     printf("bytes=%llu rounds=%d cold=%d  (GB/s = read+write = 2*bytes/t)\n", (unsigned long long)n, rounds, (int)cold);
     for (auto &v : vs) {
         std::sort(v.ms.begin(), v.ms.end());
         float med = v.ms[v.ms.size() / 2], mn = v.ms.front();
-        printf("%s  med %.4f ms  min %.4f ms  -> %7.1f GB/s (med) %7.1f (best)\n", v.name.c_str(), med, mn,
-               2.0 * n / med / 1e6, 2.0 * n / mn / 1e6);
+        printf("%s  med %.4f ms  min %.4f ms  -> %7.1f GB/s (med) %7.1f (best)%s\n", v.name.c_str(), med, mn,
+               2.0 * n / med / 1e6, 2.0 * n / mn / 1e6, v.bad ? "   ** INVALID: wrong results, timing meaningless **" : "");
     }
     return 0;
 }
