@@ -50,4 +50,36 @@ g2.replay()
 torch.cuda.synchronize()
 got = t[-(1 << 20):].cpu().numpy()
 assert np.array_equal(got, O.keystream(M.KEY_PS4, 1 << 20, n - (1 << 20))), "large graph replay"
+assert M.last_launch()["variant"] == 1, "first large launch under capture must take the static streaming shape (no ticket pair can be allocated there)"
+
+# (4) the work-queue shape: eager on two torch streams at once (each launch gets its own ticket pair from the
+# per-device ring), then captured into a graph (the pair is baked into the graph and cleans itself after every run)
+n4 = (288 << 20) + 80
+ta = torch.zeros(n4, dtype=torch.uint8, device="cuda")
+tb = torch.zeros(n4 + 4, dtype=torch.uint8, device="cuda")
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+torch.cuda.synchronize()
+for _ in range(3):  # three rounds: odd number of passes leaves the keystream in both
+    M.cycle_device(ta.data_ptr(), n4, M.KEY_PS4, 0, 0, s1.cuda_stream)
+    M.cycle_device(tb.data_ptr() + 4, n4, M.KEY_PS3, 12345, 0, s2.cuda_stream)
+assert M.last_launch()["variant"] == 2 and M.last_launch()["kernel"].startswith("modgpu_cycle_queue_kernel<")
+torch.cuda.synchronize()
+for off in (0, (100 << 20) + 7, n4 - (1 << 20)):
+    assert np.array_equal(ta[off:off + (1 << 20)].cpu().numpy(), O.keystream(M.KEY_PS4, 1 << 20, off)), ("stream 1", off)
+    assert np.array_equal(tb[4 + off:4 + off + (1 << 20)].cpu().numpy(), O.keystream(M.KEY_PS3, 1 << 20, 12345 + off)), ("stream 2", off)
+assert not tb[:4].cpu().numpy().any()
+g3 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g3):
+    M.cycle_device(ta.data_ptr(), n4, M.KEY_PS4, 0, 0, torch.cuda.current_stream().cuda_stream)
+assert M.last_launch()["variant"] == 2, "ticket ring exists now: the captured launch is the work-queue shape"
+torch.cuda.synchronize()
+for k in range(1, 4):  # ta holds the keystream: replay 1 -> zeros, 2 -> keystream, 3 -> zeros
+    g3.replay()
+    torch.cuda.synchronize()
+    tail = ta[-(1 << 20):].cpu().numpy()
+    want = np.zeros(1 << 20, np.uint8) if k % 2 else O.keystream(M.KEY_PS4, 1 << 20, n4 - (1 << 20))
+    assert np.array_equal(tail, want), f"queue-shape graph replay {k}"
+    if k % 2:
+        assert int(ta.sum(dtype=torch.int64).item()) == 0, "every byte back to zero"
+assert int(ta.sum(dtype=torch.int64).item()) == 0, "after an even number of passes in total the buffer is zero again"
 print("TORCH_INTEROP_OK")

@@ -212,6 +212,7 @@ int main(int argc, char **argv)
     ADDQX(4, 1024, 1, 16, 0, 1, 256);
     ADDQX(4, 1024, 1, 16, 18, 1, 256);
     ADDQX(2, 1024, 1, 16, 2, 1, 256);
+    ADDQX(4, 1024, 1, 18, 2, 1, 512); // 64 VGPRs: two workgroups fit a CU
     vs.push_back({0, "queue   U= 4 B=1024 COPY-ONLY (no keystream) b1=1 64 KiB chunks grid= 256", launch_queue<4, 1024, 0, 1, MODE_COPY, 16, 2, 1>, 65536, autogrid(65536, 256), {}});
     vs.push_back({0, "queue   U= 4 B=1024 NO barriers: racy ticket hand-off    64 KiB grid= 256", launch_queue<4, 1024, 0, 1, MODE_FULL, 16, 2, 0, 0>, 65536, autogrid(65536, 256), {}});
     CycleArgs a{};
