@@ -195,3 +195,35 @@ def test_device_alias_needs_a_device(modgpu):
     r = subprocess.run([sys.executable, "-c", "import modulate_amd as M; print('COUNT', M.device_count())"],
                        capture_output=True, text=True, env=env, cwd=ROOT)
     assert r.returncode == 0 and "COUNT 0" in r.stdout, r.stdout + r.stderr
+
+
+def test_queue_kernel_codegen_keeps_the_ticket_atomic_asynchronous():
+    """The work-queue kernel's ticket fetch must stay ONE plain returning atomic whose value is waited for a
+    trip later.  LLVM's atomic optimizer (on by default) rewrites it into a wave-aggregated atomic followed at
+    once by s_waitcnt vmcnt(0) -- correct, but the wave then sits out every load it has in flight, each trip.
+    The Makefile passes -amdgpu-atomic-optimizer-strategy=None for that TU; this test compiles the TU with the
+    Makefile's flags and looks at the gfx950 ISA."""
+    import shutil
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not installed")
+    csrc = os.path.join(ROOT, "modulate_amd", "csrc")
+    flags = subprocess.run(["make", "-s", "-C", csrc, "--eval", "print-kflags: ; @echo $(KERNEL_FLAGS)", "print-kflags"],
+                           capture_output=True, text=True).stdout.split()
+    assert "-amdgpu-atomic-optimizer-strategy=None" in flags, flags
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S", "--cuda-device-only",
+                        os.path.join(csrc, "cycle_kernel.hip"), "-o", "-"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = r.stdout
+    start = asm.index("_Z25modgpu_cycle_queue_kernel")
+    body = asm[asm.index(":", start):asm.index("s_endpgm", start)]
+    assert "v_mbcnt" not in body, "the atomic optimizer rewrote the ticket atomic"
+    assert body.count("global_atomic_add") == 3  # one ticket fetch per unrolled trip (2) + the exit count
+    assert "scratch_" not in body and "flat_" not in body  # no spills, LDS mailbox accessed with ds_ instructions
+    assert body.count("ds_write_b32") == 2 and body.count("ds_read_b32") == 2
+    loads = [ln for ln in body.splitlines() if "buffer_load_dwordx4" in ln]
+    stores = [ln for ln in body.splitlines() if "buffer_store_dwordx4" in ln]
+    assert loads and all(ln.rstrip().endswith(" nt") for ln in loads), loads[:2]
+    hot_stores = [ln for ln in stores if ln.rstrip().endswith("nt sc1")]
+    assert len(hot_stores) >= 8  # 4 words x 2 unrolled trips (+ the cold peel loop)
+    assert shutil.which("make")
