@@ -353,3 +353,23 @@ def test_bench_two_ranks_rehearsal(host, tmp_path):
     assert out["roofline"]["kernel"].startswith("modgpu_cycle_queue_kernel<4, 1024,") and out["roofline"]["grid"] == 256
     assert "cpu_baseline" not in out  # rank 0 at N=1 only
     assert abs(out["value"] - 2 * 3 * 2 * (320 << 20) / (out["ms_per_step"] * 3 * 1e-3) / 1e9) / out["value"] < 0.01
+
+
+def test_bench_nccl_branch_single_rank(host):
+    """The N>1 code path of bench.py with the real backend (nccl = RCCL): torch imported first, process group on the GPU,
+    barrier + MAX over ranks on device tensors -- forced on with one rank, since this box has one GPU."""
+    import json
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--part-bytes", str(320 << 20), "--force-dist", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["config"]["bit_exact_check"].startswith("pass")
+    assert out["roofline"]["kernel"].startswith("modgpu_cycle_queue_kernel<4, 1024,")
