@@ -87,10 +87,11 @@ int modgpu_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_
                         int device, void *hip_stream);
 
 /* Replaces CEncryptionCycler::Cycle (CEncryptionCycler.cpp:4-14) for a caller-owned HOST buffer,
- * on the GPU.  Pageable memory is staged (memcpy -> pinned -> H2D -> kernel -> D2H -> pinned ->
- * memcpy, chunked and overlapped); memory from modgpu_host_alloc (or any other HIP-pinned range)
- * is cycled where it lies, with no staging copy.  Synchronous: on return host_buf holds the
- * result.  Never retains or frees host_buf. */
+ * on the GPU.  Pageable memory is staged through page-locked slots owned by this library (memcpy ->
+ * slot -> kernel across PCIe on the slot -> memcpy back, chunked over several host threads and
+ * overlapped); memory from modgpu_host_alloc / modgpu_host_register is cycled where it lies by one
+ * kernel across PCIe, with no staging copy.  Synchronous: on return host_buf holds the result.
+ * Never retains or frees host_buf. */
 int modgpu_cycle_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, int device);
 
 /* The library's own host loop for the same arithmetic (closed form of CEncryptionCycler.cpp:16-25,
@@ -145,7 +146,13 @@ int modgpu_cycle_host_to_file(const uint8_t *host_src, uint64_t n, const char *p
  * Without a GPU the memory is ordinary (64-byte aligned) and everything still works. */
 int modgpu_host_alloc(void **host_ptr, uint64_t n);
 int modgpu_host_free(void *host_ptr);
-/* 1 if [p, p+n) lies inside one page-locked, device-visible allocation, else 0. */
+/* For callers that cannot change how their buffer is allocated: page-locks [host_ptr, host_ptr + n) where it
+ * lies (hipHostRegister) so that later cycles of ranges inside it take the no-copy route.  Pinning costs
+ * about as much as one staged pass over the buffer, so it pays from the second cycle on.  Unregister
+ * before freeing the memory.  Without a GPU both calls succeed and do nothing. */
+int modgpu_host_register(void *host_ptr, uint64_t n);
+int modgpu_host_unregister(void *host_ptr);
+/* 1 if [p, p+n) lies inside one page-locked, device-visible allocation or registration, else 0. */
 int modgpu_host_is_pinned(const void *p, uint64_t n);
 
 /* ---- which engine ran ---------------------------------------------------------------------- */

@@ -40,6 +40,8 @@ EXPORTS = {
     "modgpu_host_alloc": (_int, [ctypes.POINTER(_vp), _u64]),
     "modgpu_host_free": (_int, [_vp]),
     "modgpu_host_is_pinned": (_int, [_vp, _u64]),
+    "modgpu_host_register": (_int, [_vp, _u64]),
+    "modgpu_host_unregister": (_int, [_vp]),
     "modgpu_path_stats": (_int, [_vp, _int]),
     "modgpu_gpu_required": (_int, []),
 }
@@ -202,6 +204,15 @@ class PinnedBuffer:
             self.free()
         except Exception:
             pass
+
+
+def host_register(buf):
+    """Page-lock a caller-owned ndarray in place (modgpu_host_register); pair with host_unregister(buf)."""
+    _check(lib().modgpu_host_register(_host_ptr(buf), buf.size))
+
+
+def host_unregister(buf):
+    _check(lib().modgpu_host_unregister(_host_ptr(buf)))
 
 
 def hdr_decrypt_host(hdr, device=-1):

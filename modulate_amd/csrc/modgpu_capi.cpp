@@ -267,7 +267,8 @@ namespace {
 struct HostRange {
     uintptr_t base;
     uint64_t size;
-    bool pinned;   // hipHostMalloc'd (else posix_memalign: no GPU when it was allocated)
+    bool pinned;     // page-locked and device-visible (else posix_memalign: no GPU when it was allocated)
+    bool registered; // the caller's own memory, pinned in place by modgpu_host_register (never freed here)
 };
 std::mutex g_host_mu;
 std::vector<HostRange> g_host_ranges; // few, long-lived allocations: linear scan
@@ -451,7 +452,7 @@ int modgpu_host_alloc(void **host_ptr, uint64_t n)
         }
         {
             std::lock_guard<std::mutex> lock(g_host_mu);
-            g_host_ranges.push_back({reinterpret_cast<uintptr_t>(p), bytes, pinned});
+            g_host_ranges.push_back({reinterpret_cast<uintptr_t>(p), bytes, pinned, false});
         }
         *host_ptr = p;
         return MODGPU_OK;
@@ -466,7 +467,7 @@ int modgpu_host_free(void *host_ptr)
         {
             std::lock_guard<std::mutex> lock(g_host_mu);
             for (size_t i = 0; i < g_host_ranges.size(); ++i)
-                if (g_host_ranges[i].base == reinterpret_cast<uintptr_t>(host_ptr)) {
+                if (g_host_ranges[i].base == reinterpret_cast<uintptr_t>(host_ptr) && !g_host_ranges[i].registered) {
                     pinned = g_host_ranges[i].pinned;
                     g_host_ranges.erase(g_host_ranges.begin() + (long)i);
                     found = true;
@@ -476,6 +477,39 @@ int modgpu_host_free(void *host_ptr)
         if (!found) return fail(MODGPU_ERR_INVALID, "not a modgpu_host_alloc pointer");
         if (pinned) HIP_TRY(hipHostFree(host_ptr));
         else std::free(host_ptr);
+        return MODGPU_OK;
+    });
+}
+
+int modgpu_host_register(void *host_ptr, uint64_t n)
+{
+    return guarded([&]() -> int {
+        if (!host_ptr || n == 0) return fail(MODGPU_ERR_INVALID, "null or empty range");
+        if (physical_count() <= 0) return MODGPU_OK; // nothing to pin for: the host loop reads any memory
+        hipError_t e = hipHostRegister(host_ptr, n, hipHostRegisterPortable | hipHostRegisterMapped);
+        if (e != hipSuccess) return fail_hip(e, "hipHostRegister");
+        std::lock_guard<std::mutex> lock(g_host_mu);
+        g_host_ranges.push_back({reinterpret_cast<uintptr_t>(host_ptr), n, true, true});
+        return MODGPU_OK;
+    });
+}
+
+int modgpu_host_unregister(void *host_ptr)
+{
+    return guarded([&]() -> int {
+        if (!host_ptr || physical_count() <= 0) return MODGPU_OK;
+        bool found = false;
+        {
+            std::lock_guard<std::mutex> lock(g_host_mu);
+            for (size_t i = 0; i < g_host_ranges.size(); ++i)
+                if (g_host_ranges[i].base == reinterpret_cast<uintptr_t>(host_ptr) && g_host_ranges[i].registered) {
+                    g_host_ranges.erase(g_host_ranges.begin() + (long)i);
+                    found = true;
+                    break;
+                }
+        }
+        if (!found) return fail(MODGPU_ERR_INVALID, "not a modgpu_host_register range");
+        HIP_TRY(hipHostUnregister(host_ptr));
         return MODGPU_OK;
     });
 }

@@ -187,6 +187,10 @@ def test_host_alloc_without_gpu_is_plain_memory(modgpu):
     assert int(pb.array.sum()) == 700_000
     pb.free()
     assert modgpu.lib().modgpu_host_free(12345) == 1  # MODGPU_ERR_INVALID: not one of ours
+    buf = np.arange(4096, dtype=np.uint8)
+    modgpu.host_register(buf)  # no GPU: nothing to pin for, succeeds and changes nothing
+    assert modgpu.lib().modgpu_host_is_pinned(buf.ctypes.data, buf.size) == 0
+    modgpu.host_unregister(buf)
 
 
 def test_device_alias_needs_a_device(modgpu):

@@ -458,6 +458,34 @@ def test_pinned_host_buffers(gpu, oracle, mode):
         gpu.debug_set_pinned_mode(0)
 
 
+def test_host_register_pins_caller_memory_in_place(gpu, oracle):
+    """modgpu_host_register: an ordinary (numpy) buffer page-locked where it lies; sub-ranges then take the no-copy
+    route, ranges that poke out of the registration the staged one, and after unregister everything is staged again."""
+    n = (24 << 20) + 100
+    whole = oracle.splitmix_bytes(n, 42)
+    buf = whole.copy()
+    view = buf[52:52 + (20 << 20) + 7]
+    want = oracle.cycle(view.copy(), gpu.KEY_PS3)
+    gpu.host_register(buf)
+    try:
+        assert gpu.lib().modgpu_host_is_pinned(buf.ctypes.data + 52, view.size) == 1
+        assert gpu.lib().modgpu_host_is_pinned(buf.ctypes.data + n - 4, 5) == 0
+        before = gpu.path_stats()
+        gpu.cycle_host(view, gpu.KEY_PS3)
+        after = gpu.path_stats()
+        assert np.array_equal(view, want) and np.array_equal(buf[:52], whole[:52]) and np.array_equal(buf[52 + view.size:], whole[52 + view.size:])
+        assert after["direct_bytes"] == before["direct_bytes"] + view.size and after["staged_bytes"] == before["staged_bytes"]
+        assert gpu.lib().modgpu_host_free(buf.ctypes.data) == 1  # a registration is not an allocation of ours
+    finally:
+        gpu.host_unregister(buf)
+    assert gpu.lib().modgpu_host_is_pinned(buf.ctypes.data + 52, view.size) == 0
+    before = gpu.path_stats()
+    gpu.cycle_host(view, gpu.KEY_PS3)  # decrypts back, staged this time
+    after = gpu.path_stats()
+    assert np.array_equal(buf, whole) and after["staged_bytes"] == before["staged_bytes"] + view.size
+    assert gpu.lib().modgpu_host_unregister(buf.ctypes.data) == 1  # already gone
+
+
 def test_pinned_endpoints_of_file_streams(gpu, oracle, tmp_path):
     """CArk's part buffer is page-locked: file -> GPU -> pinned memory and pinned memory -> GPU -> file skip
     the memory-side copy (what LoadArkData / SaveArk do with the part cipher on, CArk.cpp:751, 883)."""
