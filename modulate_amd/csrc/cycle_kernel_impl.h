@@ -329,7 +329,8 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
 // LAUX  = cache-policy bits of the loads (AUX_NT in the product); B1 = 0 drops the barrier in front of each trip's
 //         load burst (tools/tune_cycle only)
 // B2    = 0 (tools/tune_cycle, TIMING ONLY -- results are wrong): drops the second barrier too, so the ticket
-//         hand-off races; answers what a barrier-free workgroup would gain
+//         hand-off races; answers what a barrier-free workgroup would gain.  B2 = 2 (tools/tune_cycle): the
+//         barrier sits behind the store burst instead of in front of it (waves store as they finish)
 template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int LAUX = AUX_NT, int B1 = 1, int B2 = 1>
 __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
 {
@@ -427,10 +428,14 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
         if (publish && tid == 0) // (the LDS write has landed before the barrier releases the readers)
             asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(q_next_lds + 4u * (trip & 1u)), "v"(pending) : "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (B2 != 0) __builtin_amdgcn_s_barrier();
+        if constexpr (B2 == 1) __builtin_amdgcn_s_barrier();
         if (tid == 0) pending = __hip_atomic_fetch_add(a.queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
+        if constexpr (B2 == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
         ++trip;
         stamp(trip);
     };

@@ -236,6 +236,10 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
     a.base_body = lcg::mulmod(a.base_body, lcg::powmod(lcg::A, lcg::PERIOD - a.lead % lcg::PERIOD));
     uint64_t chunks = (a.lead + body_bytes + chunk - 1) / chunk;
     uint64_t cap = p.variant == CYCLE_SMALL ? kSmallGridMax : large_grid();
+    // With chunks handed out by tickets any grid finishes the job, and the memory system does best with fewer
+    // streams than CUs: 25 workgroups per 32 CUs (200 on MI355X) -- measured plateau 184..208, +1.6 % at 4 GiB and
+    // +2.4 % at 402 MiB over one per CU; 160 and below fall off (profiles/r02_tune_cycle_queue_grid.txt).
+    if (p.variant == CYCLE_QUEUE) cap = std::max<uint64_t>(1, cap * 25 / 32);
     if (over_pcie) cap = std::min<uint64_t>(cap, kPcieGridMax);
     const uint32_t grid_cap = g_grid_cap.load(std::memory_order_relaxed);
     if (grid_cap >= 1 && grid_cap < cap) cap = grid_cap;

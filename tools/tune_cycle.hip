@@ -213,6 +213,24 @@ int main(int argc, char **argv)
     ADDQX(4, 1024, 1, 16, 18, 1, 256);
     ADDQX(2, 1024, 1, 16, 2, 1, 256);
     ADDQX(4, 1024, 1, 18, 2, 1, 512); // 64 VGPRs: two workgroups fit a CU
+    ADDQX(4, 1024, 1, 18, 2, 1, 240);
+    ADDQX(4, 1024, 1, 18, 2, 1, 224);
+    ADDQX(4, 1024, 1, 18, 2, 1, 208);
+    ADDQX(4, 1024, 1, 18, 2, 1, 200);
+    ADDQX(4, 1024, 1, 18, 2, 1, 192);
+    ADDQX(4, 1024, 1, 18, 2, 1, 184);
+    ADDQX(4, 1024, 1, 18, 2, 1, 176);
+    ADDQX(4, 1024, 1, 18, 2, 1, 160);
+    ADDQX(4, 1024, 1, 18, 2, 1, 144);
+    ADDQX(4, 1024, 1, 18, 2, 1, 128);
+    ADDQX(4, 1024, 2, 18, 2, 1, 192);
+    ADDQX(4, 1024, 2, 18, 2, 1, 160);
+    ADDQX(8, 1024, 1, 18, 2, 1, 192);
+    ADDQX(8, 1024, 1, 18, 2, 1, 160);
+    ADDQX(8, 512, 1, 18, 2, 1, 192);
+    vs.push_back({0, "queue   U= 4 B=1024 st=18 b1=0, barrier BEHIND the store burst 64 KiB grid= 256", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 0, 2>, 65536, autogrid(65536, 256), {}});
+    vs.push_back({0, "queue   U= 4 B=1024 st=18 b1=1, barrier BEHIND the store burst 64 KiB grid= 256", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 2>, 65536, autogrid(65536, 256), {}});
+    vs.push_back({0, "queue   U= 8 B= 512 st=18 b1=0, barrier BEHIND the store burst 64 KiB grid= 256", launch_queue<8, 512, 0, 1, MODE_FULL, 18, 2, 0, 2>, 65536, autogrid(65536, 256), {}});
     vs.push_back({0, "queue   U= 4 B=1024 COPY-ONLY (no keystream) b1=1 64 KiB chunks grid= 256", launch_queue<4, 1024, 0, 1, MODE_COPY, 16, 2, 1>, 65536, autogrid(65536, 256), {}});
     vs.push_back({0, "queue   U= 4 B=1024 NO barriers: racy ticket hand-off    64 KiB grid= 256", launch_queue<4, 1024, 0, 1, MODE_FULL, 16, 2, 0, 0>, 65536, autogrid(65536, 256), {}});
     CycleArgs a{};
