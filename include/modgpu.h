@@ -82,7 +82,10 @@ const char *modgpu_last_error(void);
 /* Replaces the loop body of CEncryptionCycler::Cycle (CEncryptionCycler.cpp:9-13) for a buffer
  * that is already device-resident.  `dev_buf` may have any byte alignment (the reference's
  * callers pass buf+4).  Asynchronous on `hip_stream` (a hipStream_t; NULL = the device's
- * null stream); the caller synchronises.  This is the entry point the roofline is measured on. */
+ * null stream); the caller synchronises.  This is the entry point the roofline is measured on.
+ * Allocation-free and capturable into a hipGraph; a captured launch of a large buffer carries its own
+ * scheduling scratch word, so one captured launch must not run twice at the same time (replaying it
+ * back to back, or capturing it twice, is fine). */
 int modgpu_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off,
                         int device, void *hip_stream);
 

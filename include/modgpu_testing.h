@@ -49,6 +49,11 @@ void modgpu_debug_set_pinned_mode(int mode);
  * (no DMA submissions, no device slot).  Same bytes; tools/sweep_pinned.py times them. */
 void modgpu_debug_set_staged_mode(int mode);
 
+/* The host-path tunables as the library latched them at load (after clamping): out[0] = pipelines
+ * (MODGPU_HOST_PIPES), out[1] = largest slot in bytes (MODGPU_HOST_CHUNK_MB), out[2] = largest buffer cycled in
+ * one pinned slot without chunking (MODGPU_HOST_ZEROCOPY_KB, never above out[1]), out[3] = DMA ring depth. */
+void modgpu_debug_host_tunables(uint64_t out[4]);
+
 /* Identity of the device code this library carries: hex SHA-256 over the kernel sources it was
  * built from (cycle_kernel_impl.h, cycle_kernel.hip, cycle_kernel.h, lcg.h), fixed at build time.
  * profiles/pmc_summary.json records it so that counter figures are never replayed for other code. */

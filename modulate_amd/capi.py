@@ -70,6 +70,7 @@ TESTING_EXPORTS = {
     "modgpu_debug_set_pinned_mode": (None, [_int]),
     "modgpu_debug_set_staged_mode": (None, [_int]),
     "modgpu_kernel_source_hash": (ctypes.c_char_p, []),
+    "modgpu_debug_host_tunables": (None, [ctypes.POINTER(_u64)]),
 }
 
 
@@ -174,6 +175,13 @@ def debug_set_pinned_mode(mode=0):
 def debug_set_staged_mode(mode=0):
     """Test hook: 0 default, 1 DMA, 2 kernel over PCIe on the pinned slot, for staged (pageable / file) chunks."""
     lib().modgpu_debug_set_staged_mode(mode)
+
+
+def host_tunables():
+    """The host-path tunables as latched (and clamped) at library load."""
+    out = (_u64 * 4)()
+    lib().modgpu_debug_host_tunables(out)
+    return {"pipes": int(out[0]), "chunk_bytes": int(out[1]), "zerocopy_max_bytes": int(out[2]), "ring": int(out[3])}
 
 
 def kernel_source_hash():

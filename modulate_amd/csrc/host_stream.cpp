@@ -32,6 +32,7 @@
 #include <thread>
 #include <vector>
 
+#include "../../include/modgpu_testing.h"
 #include "modgpu_internal.h"
 
 namespace modgpu {
@@ -328,6 +329,14 @@ struct Fd { // closes on scope exit
 } // namespace
 
 extern "C" {
+
+void modgpu_debug_host_tunables(uint64_t out[4])
+{
+    out[0] = (uint64_t)kPipes;
+    out[1] = kChunk;
+    out[2] = kZeroCopyMax;
+    out[3] = (uint64_t)kRing;
+}
 
 int modgpu_cycle_file(const char *src_path, const char *dst_path, int32_t key, uint64_t stream_off, int device)
 {

@@ -231,3 +231,24 @@ def test_queue_kernel_codegen_keeps_the_ticket_atomic_asynchronous():
     hot_stores = [ln for ln in stores if ln.rstrip().endswith("nt sc1")]
     assert len(hot_stores) >= 8  # 4 words x 2 unrolled trips (+ the cold peel loop)
     assert shutil.which("make")
+
+
+@pytest.mark.parametrize("env,want", [
+    ({}, {"pipes": 8, "chunk_bytes": 8 << 20, "zerocopy_max_bytes": 1 << 20, "ring": 4}),
+    # a zero-copy limit above the slot size used to overrun the pinned staging slot
+    ({"MODGPU_HOST_CHUNK_MB": "1", "MODGPU_HOST_ZEROCOPY_KB": "2048"}, {"chunk_bytes": 1 << 20, "zerocopy_max_bytes": 1 << 20}),
+    ({"MODGPU_HOST_ZEROCOPY_KB": "999999999"}, {"zerocopy_max_bytes": 8 << 20}),
+    ({"MODGPU_HOST_PIPES": "99", "MODGPU_HOST_CHUNK_MB": "0", "MODGPU_HOST_RING": "9", "MODGPU_HOST_ZEROCOPY_KB": "0"},
+     {"pipes": 16, "chunk_bytes": 1 << 20, "ring": 4, "zerocopy_max_bytes": 0}),
+])
+def test_host_tunables_are_clamped_at_load(env, want):
+    code = "import json, modulate_amd as M; print('T', json.dumps(M.host_tunables()))"
+    e = {k: v for k, v in os.environ.items() if not k.startswith("MODGPU_HOST_")}
+    e.update(env, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import json
+    got = json.loads(r.stdout.split("T ", 1)[1])
+    for k, v in want.items():
+        assert got[k] == v, (k, got)
+    assert got["zerocopy_max_bytes"] <= got["chunk_bytes"]
