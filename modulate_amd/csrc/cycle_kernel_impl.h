@@ -320,8 +320,8 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
 //
 // Ticket hand-off inside a workgroup: lane 0 issues the returning atomic right after a trip's second barrier
 // (in front of that trip's store burst, so waiting for it later never waits for those stores), publishes the
-// value through one LDS word before the NEXT trip's second barrier, and every wave reads it after that
-// barrier.  a.queue[0] is the ticket counter, a.queue[1] counts workgroups that are done; the last one out
+// value through an LDS word (two, used alternately) before the NEXT trip's second barrier, and every wave reads it
+// after that barrier.  a.queue[0] is the ticket counter, a.queue[1] counts workgroups that are done; the last one out
 // zeroes both, so the pair is clean for the next launch without a memset.
 // DEPTH = chunks of loads a workgroup keeps in flight ahead of the one it computes (1 = ping-pong as above)
 // MODE  = MODE_FULL in the product; MODE_COPY (tools/tune_cycle) is the same loop without the keystream: the
@@ -345,8 +345,9 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
     const uint32_t G = gridDim.x;
     // Two LDS words, used alternately: a trip's ticket is written before that trip's barrier and read after it, and
     // the same word is written again two trips later -- i.e. behind the NEXT trip's barrier, which no wave can reach
-    // before it has done this trip's read.  (With a single word a wave held up between the barrier and its read
-    // could in principle be overtaken by lane 0's next write, there being no barrier in front of the loads.)
+    // before it has done this trip's read.  (With a single word, correctness would lean on the other barrier, the
+    // one in front of the loads, which is a tuning choice: without it a wave held up between this barrier and its
+    // read can be overtaken by lane 0's next write -- tools/tune_cycle's INVALID row shows what that looks like.)
     __shared__ uint32_t q_next[2];
     uint32_t trip = 0;
     [[maybe_unused]] auto stamp = [&](uint32_t slot) {
