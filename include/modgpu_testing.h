@@ -49,6 +49,11 @@ void modgpu_debug_set_pinned_mode(int mode);
  * (no DMA submissions, no device slot).  Same bytes; tools/sweep_pinned.py times them. */
 void modgpu_debug_set_staged_mode(int mode);
 
+/* Failure injection: the next `count` host-buffer / file calls fail with MODGPU_ERR_HIP before they touch
+ * anything, as if a HIP call had failed at set-up.  Lets the tests drive modgpu_cycle_auto_host's second branch
+ * ("a GPU is visible but the attempt failed") on a machine whose GPU works. */
+void modgpu_debug_inject_failures(int count);
+
 /* The host-path tunables as the library latched them at load (after clamping): out[0] = pipelines
  * (MODGPU_HOST_PIPES), out[1] = largest slot in bytes (MODGPU_HOST_CHUNK_MB), out[2] = largest buffer cycled in
  * one pinned slot without chunking (MODGPU_HOST_ZEROCOPY_KB, never above out[1]), out[3] = DMA ring depth. */

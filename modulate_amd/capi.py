@@ -71,6 +71,7 @@ TESTING_EXPORTS = {
     "modgpu_debug_set_staged_mode": (None, [_int]),
     "modgpu_kernel_source_hash": (ctypes.c_char_p, []),
     "modgpu_debug_host_tunables": (None, [ctypes.POINTER(_u64)]),
+    "modgpu_debug_inject_failures": (None, [_int]),
 }
 
 
@@ -175,6 +176,11 @@ def debug_set_pinned_mode(mode=0):
 def debug_set_staged_mode(mode=0):
     """Test hook: 0 default, 1 DMA, 2 kernel over PCIe on the pinned slot, for staged (pageable / file) chunks."""
     lib().modgpu_debug_set_staged_mode(mode)
+
+
+def debug_inject_failures(count):
+    """Test hook: the next `count` host-buffer / file calls fail with MODGPU_ERR_HIP before touching anything."""
+    lib().modgpu_debug_inject_failures(count)
 
 
 def host_tunables():

@@ -39,6 +39,7 @@ namespace modgpu {
 
 std::atomic<int> g_pinned_mode{0};
 std::atomic<int> g_staged_mode{0};
+std::atomic<int> g_inject_failures{0}; // modgpu_debug_inject_failures
 
 namespace {
 
@@ -210,6 +211,8 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     int dev = 0;
     int rc = resolve_device(device, &dev);
     if (rc) return rc;
+    if (g_inject_failures.load(std::memory_order_relaxed) > 0 && g_inject_failures.fetch_sub(1) > 0)
+        return fail(MODGPU_ERR_HIP, "injected failure (modgpu_debug_inject_failures)");
     // keys == 0 mod m give the identity: nothing to do in place, a plain copy otherwise
     const bool identity = (int64_t)key % 0x7FFFFFFFll == 0;
     const bool in_place = src.mem && src.mem == dst.mem;
@@ -237,10 +240,10 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
         if (rc) return rc;
         void *mapped = nullptr;
         HIP_TRY(hipHostGetDevicePointer(&mapped, src.mem, 0));
-        if (touched) *touched = true;
         rc = cycle_device_impl(mapped, n, key, stream_off, s.stream[0], /*over_pcie=*/true);
+        if (rc) return rc; // nothing was launched: the caller's pages are as they were
+        if (touched) *touched = true;
         hipError_t e = hipStreamSynchronize(s.stream[0]);
-        if (rc) return rc;
         if (e != hipSuccess) return fail_hip(e, "hipStreamSynchronize (kernel over PCIe)");
         account();
         return MODGPU_OK;
@@ -329,6 +332,8 @@ struct Fd { // closes on scope exit
 } // namespace
 
 extern "C" {
+
+void modgpu_debug_inject_failures(int count) { g_inject_failures.store(count > 0 ? count : 0); }
 
 void modgpu_debug_host_tunables(uint64_t out[4])
 {

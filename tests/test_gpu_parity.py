@@ -287,6 +287,50 @@ def test_config2_4gib_part_roundtrip(gpu, oracle, golden):
     dbuf.free()
 
 
+_FALLBACK_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import modulate_amd as M
+from oracle import oracle as O
+strict = M.gpu_required()
+assert M.device_count() >= 1
+pt = O.splitmix_bytes(3_000_001, 8)
+want = O.cycle(pt.copy(), O.KEY_PS4)
+for make in (lambda: pt.copy(), None):           # pageable, then page-locked caller memory
+    if make is None:
+        pb = M.PinnedBuffer(pt.size); pb.array[:] = pt; buf = pb.array
+    else:
+        buf = make()
+    M.debug_inject_failures(1)
+    try:
+        M.cycle_auto_host(buf, M.KEY_PS4)
+        assert not strict, "MODGPU_REQUIRE_GPU=1 must not compute on the host"
+        assert np.array_equal(buf, want)             # the host loop finished the call, bit-exact
+    except M.ModGpuError as e:
+        assert strict and e.code == 3 and np.array_equal(buf, pt), (e.code, "buffer must be untouched")
+    M.cycle_auto_host(buf, M.KEY_PS4)                # no injection: the GPU serves it
+    assert np.array_equal(buf, pt if not strict else want)
+st = M.path_stats()
+assert st["auto_fallbacks"] == (0 if strict else 2) and st["scalar_calls"] == (0 if strict else 2), st
+assert st["gpu_calls"] == 2, st
+try:                                                 # the GPU-only entry point never falls back, strict or not
+    M.debug_inject_failures(1); M.cycle_host(pt.copy(), M.KEY_PS4); raise SystemExit("cycle_host computed")
+except M.ModGpuError as e:
+    assert e.code == 3
+print("FALLBACK_OK", strict)
+"""
+
+
+@pytest.mark.parametrize("strict", ["0", "1"])
+def test_auto_entry_point_when_a_gpu_call_fails(gpu, strict):
+    """modgpu_cycle_auto_host's second branch ("else if (mod_cycle_host(...) != 0) cpu_loop()"): a GPU is
+    visible but the attempt fails at set-up (injected).  Without MODGPU_REQUIRE_GPU the library's host loop finishes
+    the call bit-exact and is counted; with it the error comes back and the buffer is untouched."""
+    e = dict(os.environ, MODGPU_REQUIRE_GPU=strict)
+    r = subprocess.run([sys.executable, "-c", _FALLBACK_CHILD % ROOT], capture_output=True, text=True, env=e, timeout=600)
+    assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 FUZZ_CASES = [("large", 1), ("large", 2), ("large", 3), ("large", 7), ("large", None), ("small", 1), ("small", 5), ("small", None),
               ("queue", 1), ("queue", 2), ("queue", 3), ("queue", 5), ("queue", 16), ("queue", None)]
 
