@@ -1,0 +1,93 @@
+"""Property-based checks (hypothesis), CPU only: the product's host loop against the oracle over random keys,
+lengths, alignments and 64-bit stream offsets; the algebra the GPU path relies on (involution, a stream cut at any
+byte equals one call, periodicity); and the C++ header writer against the Python restatement on random tables."""
+import os
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from oracle import ark_header as AH
+
+needs_host_loop = pytest.mark.skipif(os.environ.get("MODGPU_REQUIRE_GPU", "0") not in ("", "0"),
+                                     reason="MODGPU_REQUIRE_GPU forbids the host loop in this process")
+COMMON = dict(deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+keys = st.one_of(st.sampled_from([0x90CFC0AB, 0xC64EED30, 0, 1, 0x7FFFFFFF, 0x80000000, 0x80000001, 0xFFFFFFFF, 0x7FFFFFFE]),
+                 st.integers(0, 0xFFFFFFFF))
+offsets = st.one_of(st.integers(0, 1 << 20), st.integers(0, (1 << 64) - 1),
+                    st.sampled_from([0x7FFFFFFE - 3, 0x7FFFFFFE, (1 << 32) - 1, 1 << 32, (1 << 64) - 1]))
+
+
+@needs_host_loop
+@settings(max_examples=150, **COMMON)
+@given(key=keys, n=st.integers(0, 3000), off=offsets, lead=st.integers(0, 17), seed=st.integers(0, 1 << 30))
+def test_host_loop_equals_oracle(modgpu, oracle, key, n, off, lead, seed):
+    whole = oracle.splitmix_bytes(n + lead + 9, seed)
+    got, want = whole.copy(), whole.copy()
+    modgpu.cycle_scalar_host(got[lead:lead + n], key, off)
+    oracle.cycle_at(want[lead:lead + n], key, off)
+    assert np.array_equal(got, want)
+
+
+@needs_host_loop
+@settings(max_examples=60, **COMMON)
+@given(key=keys, n=st.integers(1, 5000), off=offsets, cut=st.floats(0, 1), seed=st.integers(0, 1 << 30))
+def test_involution_and_split_stream(modgpu, oracle, key, n, off, cut, seed):
+    pt = oracle.splitmix_bytes(n, seed)
+    one = modgpu.cycle_scalar_host(pt.copy(), key, off)
+    assert np.array_equal(modgpu.cycle_scalar_host(one.copy(), key, off), pt)  # the cipher is its own inverse
+    k = int(cut * n)
+    two = pt.copy()
+    modgpu.cycle_scalar_host(two[:k], key, off)
+    modgpu.cycle_scalar_host(two[k:], key, (off + k) & ((1 << 64) - 1))  # a stream cut at any byte == one call
+    if off + k < (1 << 64):  # (positions do not wrap at 2^64 in the reference's terms: skip the wrap case)
+        assert np.array_equal(two, one)
+
+
+@settings(max_examples=200, **COMMON)
+@given(key=keys, i=st.integers(0, (1 << 64) - 1))
+def test_state_at_matches_oracle_and_period(modgpu, oracle, key, i):
+    s = modgpu.state_at(key, i)
+    assert s == oracle.state_at(key, i) & 0xFFFFFFFF
+    assert 1 <= s <= 0x7FFFFFFF
+    if i + oracle.PERIOD < (1 << 64):
+        assert modgpu.state_at(key, i + oracle.PERIOD) == s  # the keystream has period 2^31 - 2
+
+
+names = st.lists(st.text(alphabet="abcXYZ019_./", min_size=1, max_size=40).filter(
+    lambda s: not s.startswith("/") and not s.endswith("/") and "//" not in s), min_size=1, max_size=60, unique=True)
+
+
+@settings(max_examples=80, **COMMON)
+@given(names=names, data=st.data())
+def test_header_writer_equals_restatement_on_random_tables(names, data):
+    from modulate_amd import host as H
+    H.lib()
+    H.set_flags(overwrite=True, ignore_new=True, pack_all=False, verbose=False)
+    sizes = [data.draw(st.integers(0, 5000)) for _ in names]
+    n_arks = data.draw(st.integers(1, 5))
+    ps4 = data.draw(st.booleans())
+    H.select_platform(ps4)
+    try:
+        a = H.Ark()
+        a.construct_from_table(names, sizes, n_arks, "p")
+        a.build_from_memory(np.zeros(sum(sizes), np.uint8))
+        offs, parts = AH.split_into_arks(sizes, AH.even_plan(sum(sizes), n_arks))
+        assert a.ark_sizes() == parts and [f["offset"] for f in a.files()] == offs
+        img = a.serialise_header(encrypt=False).tobytes()
+        assert img == AH.serialise(names, sizes, offs, parts, a.ark_paths(), ps4)
+        p = AH.parse(img)
+        assert p["end"] == len(img) and sorted(f["name"] for f in p["files"]) == sorted(names)
+        for nm in names:
+            assert p["files"][AH.lookup(p, nm)]["name"] == nm  # the header's own hash chains find every entry
+        if os.environ.get("MODGPU_REQUIRE_GPU", "0") in ("", "0"):  # encrypt + decrypt through Cycle (host loop here), then parse
+            b = H.Ark()
+            b.parse_header(a.serialise_header(encrypt=True))
+            assert [(f["name"], f["size"], f["offset"], f["flags1"]) for f in b.files()] == \
+                [(f["name"], f["size"], f["offset"], f["flags1"]) for f in p["files"]]
+            assert b.ark_sizes() == parts
+            b.close()
+        a.close()
+    finally:
+        H.select_platform(True)
