@@ -375,6 +375,41 @@ def test_fuzz_forced_shapes(gpu, oracle, case):
         gpu.debug_set_launch(None, 0)
 
 
+def test_queue_kernel_soak(gpu, oracle):
+    """The ticket hand-off under many launches and grid sizes: 2 000 back-to-back work-queue launches over a
+    misaligned 300 MiB span (an even number: the cipher is an involution, so any chunk ever skipped or done twice
+    leaves a mismatch behind), then grids from 1 to 200 workgroups -- many trips per workgroup down to one -- each
+    checked over the whole buffer, and one odd pass against the oracle's keystream."""
+    n, base = (300 << 20) + 77, 52
+    pt = oracle.splitmix_bytes(n + 128, 4242)
+    dbuf = gpu.DeviceBuffer(n + 128)
+    dbuf.upload(pt)
+    for _ in range(2000):
+        dbuf.cycle(0xC64EED30, n=n, offset=base, stream_off=999)
+    dbuf.sync()
+    assert gpu.last_launch()["variant"] == 2 and gpu.last_launch()["grid"] == 200
+    assert np.array_equal(dbuf.download(), pt)
+    try:
+        for grid in (1, 2, 3, 7, 64, 199, 256):
+            gpu.debug_set_launch("queue", grid)
+            for _ in range(2 if grid > 3 else 1):
+                dbuf.cycle(0xC64EED30, n=n, offset=base, stream_off=999)
+                dbuf.cycle(0xC64EED30, n=n, offset=base, stream_off=999)
+            dbuf.sync()
+            assert gpu.last_launch()["grid"] == min(grid, 200)  # the cap only lowers the library's own choice
+            assert np.array_equal(dbuf.download(), pt), grid
+    finally:
+        gpu.debug_set_launch(None, 0)
+    dbuf.cycle(0xC64EED30, n=n, offset=base, stream_off=999)
+    dbuf.sync()
+    got = dbuf.download()
+    assert np.array_equal(got[:base], pt[:base]) and np.array_equal(got[base + n:], pt[base + n:])
+    for off in (0, 65536 - 52, (150 << 20) + 3, n - (1 << 20)):
+        ln = min(1 << 20, n - off)
+        assert np.array_equal(got[base + off:base + off + ln] ^ pt[base + off:base + off + ln], oracle.keystream(0xC64EED30, ln, 999 + off)), off
+    dbuf.free()
+
+
 def test_part_files_streamed_through_gpu(gpu, oracle, tmp_path):
     """a part file read -> GPU -> written (modgpu_cycle_file / _file_to_host /
     _host_to_file) equals the oracle's Cycle of the same bytes; in place, windowed, multi-pipeline."""
