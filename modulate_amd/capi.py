@@ -1,6 +1,6 @@
 """ctypes binding over libmodgpu.so -- every call goes through the C ABI of include/modgpu.h.
 
-No fallback: if the library is missing or a call fails, ModGpuError is raised.
+Nothing is computed in Python: if the library is missing or a call fails, ModGpuError is raised.
 """
 import ctypes
 import os
@@ -94,7 +94,7 @@ def lib():
     if _lib is None:
         path = lib_path()
         if not os.path.exists(path):
-            raise ModGpuError(-1, f"{path} not built: run `make -C modulate_amd/csrc` (there is no CPU fallback)")
+            raise ModGpuError(-1, f"{path} not built: run `make -C modulate_amd/csrc` (the Python package has no implementation of its own)")
         L = ctypes.CDLL(path)
         for name, (res, args) in list(EXPORTS.items()) + list(TESTING_EXPORTS.items()):
             fn = getattr(L, name)
