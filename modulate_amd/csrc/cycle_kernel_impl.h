@@ -331,11 +331,7 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
 // B2    = 0 (tools/tune_cycle, TIMING ONLY -- results are wrong): drops the second barrier too, so the ticket
 //         hand-off races; answers what a barrier-free workgroup would gain.  B2 = 2 (tools/tune_cycle): the
 //         barrier sits behind the store burst instead of in front of it (waves store as they finish)
-// XEVEN / XODD (tools/tune_cycle only; 0 = off): at most that many workgroups stay active on each XCD whose XCC id is
-//         even / odd, the rest retire at once -- an experiment on WHERE the streams should run, given that the
-//         XCDs are not equally fast.  Launch with one workgroup per CU.
-template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int LAUX = AUX_NT, int B1 = 1, int B2 = 1,
-          int XEVEN = 0, int XODD = 0>
+template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int LAUX = AUX_NT, int B1 = 1, int B2 = 1>
 __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
 {
     static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
@@ -345,26 +341,8 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
     constexpr int NB = DEPTH + 1;     // register buffers: one being computed, DEPTH being loaded
     constexpr int PREFIX = DEPTH + 2; // static chunks per workgroup: a ticket fetched in trip j feeds trip j + PREFIX
     const uint32_t tid = threadIdx.x;
-    uint32_t blk = blockIdx.x;
-    uint32_t G = gridDim.x;
-    [[maybe_unused]] bool keep = true;
-    if constexpr (XEVEN != 0 || XODD != 0) {
-        // queue[4 + xcc]: arrivals per XCD; queue[2]: rank among the workgroups that stay.  The static prefix is
-        // then laid out over the active workgroups only (8 XCDs x 32 CUs assumed: 4*XEVEN + 4*XODD of them).
-        __shared__ uint32_t x_rank[2];
-        if (tid == 0) {
-            const uint32_t xcc = __builtin_amdgcn_s_getreg((20 | (0 << 6) | (3 << 11))) & 7u;
-            const uint32_t limit = (xcc & 1u) ? (uint32_t)XODD : (uint32_t)XEVEN;
-            const uint32_t arrived = atomicAdd(a.queue + 4 + xcc, 1u);
-            const bool stay = arrived < limit;
-            x_rank[0] = stay ? atomicAdd(a.queue + 2, 1u) : 0xFFFFFFFFu;
-        }
-        __syncthreads();
-        keep = x_rank[0] != 0xFFFFFFFFu;
-        blk = x_rank[0];
-        G = 4u * XEVEN + 4u * XODD;
-    }
-    const uint32_t G_launched = gridDim.x;
+    const uint32_t blk = blockIdx.x;
+    const uint32_t G = gridDim.x;
     // Two LDS words, used alternately: a trip's ticket is written before that trip's barrier and read after it, and
     // the same word is written again two trips later -- i.e. behind the NEXT trip's barrier, which no wave can reach
     // before it has done this trip's read.  (With a single word, correctness would lean on the other barrier, the
@@ -381,7 +359,7 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
         if (tid == 0) a.trace[blk * 32 + 31] = __builtin_amdgcn_s_getreg((20 | (0 << 6) | (3 << 11)));
         stamp(0);
     }
-    if (blockIdx.x == 0 && tid < 32) cycle_edges(a, tid);
+    if (blk == 0 && tid < 32) cycle_edges(a, tid);
 
     const uint64_t lead = a.lead;
     const uint64_t end = lead + a.body_words * lcg::WORD;
@@ -402,7 +380,7 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
     // chunk 0 is cut at the front when the body is not chunk-aligned: workgroup 0 peels it off (see
     // modgpu_cycle_kernel), and chunk numbering for everybody starts at 1
     const uint32_t first = lead != 0 ? 1u : 0u;
-    if (blockIdx.x == 0 && lead != 0) {
+    if (blk == 0 && lead != 0) {
         const uint64_t inside = end < CHUNK ? end - lead : CHUNK - lead;
         auto r = __builtin_amdgcn_make_buffer_rsrc(static_cast<uint8_t *>(a.body), 0, (int)inside, 0x00020000);
         uint32_t su = lane0;
@@ -475,7 +453,7 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
 #pragma unroll
     for (int i = 0; i < NB; ++i) cq[i] = first + blk + (uint32_t)i * G;
     const uint32_t last_static = first + blk + (uint32_t)NB * G; // position PREFIX-1, enters cq after trip 0
-    if (keep && cq[0] < n_chunks) {
+    if (cq[0] < n_chunks) {
         u32x4 d[NB][U];
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) load(d[i], cq[i]);
@@ -502,13 +480,9 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
     // leave: this workgroup's ticket atomics have all returned; the last workgroup out resets the pair
     if (tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (atomicAdd(a.queue + 1, 1u) == G_launched - 1) {
+        if (atomicAdd(a.queue + 1, 1u) == G - 1) {
             __hip_atomic_store(a.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if constexpr (XEVEN != 0 || XODD != 0) {
-                __hip_atomic_store(a.queue + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (int x = 0; x < 8; ++x) __hip_atomic_store(a.queue + 4 + x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
     }
 }

@@ -41,9 +41,9 @@ template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = 16, int SYNC
     hipLaunchKernelGGL((modgpu_cycle_kernel<U, BLOCK, ALG, PIPE, MODE, SAUX, SYNC, TRACE, LDSW>), dim3(grid), dim3(BLOCK), 0, st, a);
 }
 
-template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int SAUX = 16, int LAUX = 2, int B1 = 1, int B2 = 1, int XEVEN = 0, int XODD = 0> void launch_queue(const CycleArgs &a, uint32_t grid, hipStream_t st)
+template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int SAUX = 16, int LAUX = 2, int B1 = 1, int B2 = 1> void launch_queue(const CycleArgs &a, uint32_t grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, 1, SAUX, TRACE, DEPTH, MODE, LAUX, B1, B2, XEVEN, XODD>), dim3(grid), dim3(BLOCK), 0, st, a);
+    hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, 1, SAUX, TRACE, DEPTH, MODE, LAUX, B1, B2>), dim3(grid), dim3(BLOCK), 0, st, a);
 }
 
 // `tune_cycle trace <bytes> [grid]`: where a launch's time goes.  Runs the shipped streaming shape with
@@ -213,21 +213,6 @@ int main(int argc, char **argv)
     ADDQX(4, 1024, 1, 16, 18, 1, 256);
     ADDQX(2, 1024, 1, 16, 2, 1, 256);
     ADDQX(4, 1024, 1, 18, 2, 1, 512); // 64 VGPRs: two workgroups fit a CU
-#define ADDXCD(XE, XO)                                                                                      \
-    do {                                                                                                     \
-        char b_[160];                                                                                        \
-        snprintf(b_, sizeof b_, "queue   U= 4 B=1024 st=18: %2d workgroups on even XCDs, %2d on odd (of 32 launched each)", XE, XO); \
-        vs.push_back({0, b_, launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, XE, XO>, 65536, 256u, {}}); \
-    } while (0)
-    ADDXCD(25, 25);
-    ADDXCD(32, 18);
-    ADDXCD(18, 32);
-    ADDXCD(30, 20);
-    ADDXCD(20, 30);
-    ADDXCD(28, 22);
-    ADDXCD(22, 28);
-    ADDXCD(32, 24);
-    ADDXCD(24, 32);
     ADDQX(4, 1024, 1, 18, 2, 1, 240);
     ADDQX(4, 1024, 1, 18, 2, 1, 224);
     ADDQX(4, 1024, 1, 18, 2, 1, 208);
@@ -251,7 +236,6 @@ int main(int argc, char **argv)
     CycleArgs a{};
     CHECK(hipMalloc(&a.queue, 64));
     CHECK(hipMemset(a.queue, 0, 64));
-    if (n < 256ull * 3 * 65536) printf("note: the per-XCD variants assume at least 3 chunks per launched workgroup\n");
     a.head_ptr = buf; a.head_n = 0; a.body = buf; a.body_words = n / 16; a.tail_ptr = buf + n; a.tail_n = 0; a.lead = 0;
     const uint32_t base0 = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
     a.base_head = a.base_body = a.base_tail = base0;
