@@ -1,0 +1,139 @@
+// tools/ubench_queue_rw.hip -- what the memory system gives the work-queue access pattern when it only reads, only
+// writes, or copies in place: the ceilings the cycle kernel (read + compute + write in place) sits under.
+// Same schedule as modgpu_cycle_queue_kernel (64 KiB chunks, 1024-thread workgroups, static prefix of 3 + tickets
+// fetched a trip ahead, nt loads, sc1 nt stores, both workgroup barriers), no arithmetic.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-atomic-optimizer-strategy=None tools/ubench_queue_rw.hip -o tools/ubench_queue_rw
+// Run:   tools/ubench_queue_rw [bytes=4294967296] [grid=200]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
+enum { READ = 0, WRITE = 1, COPY = 2 };
+constexpr int U = 4, BLOCK = 1024;
+constexpr uint32_t SUB = BLOCK * 16, CHUNK = U * SUB;
+
+template <int MODE> __global__ __launch_bounds__(BLOCK) void rw_kernel(uint8_t *buf, uint64_t bytes, uint32_t *queue, uint32_t *sink)
+{
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x, G = gridDim.x;
+    __shared__ uint32_t q_next[2];
+    const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&q_next[0];
+    const uint32_t n_chunks = (uint32_t)((bytes + CHUNK - 1) / CHUNK), voff = tid * 16, one = 1u;
+    uint32_t trip = 0, pending = 0;
+    u32x4 acc = {0, 0, 0, 0};
+    auto rsrc_at = [&](uint32_t c) {
+        const uint64_t o = (uint64_t)c * CHUNK, left = o < bytes ? bytes - o : 0;
+        return __builtin_amdgcn_make_buffer_rsrc(buf + o, 0, (int)(left < CHUNK ? left : CHUNK), 0x00020000);
+    };
+    auto load = [&](u32x4(&d)[U], uint32_t c) {
+        if constexpr (MODE == WRITE) {
+            for (int u = 0; u < U; ++u) d[u] = u32x4{tid, c, (uint32_t)u, trip};
+        } else {
+            auto r = rsrc_at(c);
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, 2);
+        }
+    };
+    auto process_store = [&](u32x4(&d)[U], uint32_t c, bool publish) {
+        auto r = rsrc_at(c);
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = ~d[u];
+        if (publish && tid == 0) asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(lds + 4u * (trip & 1u)), "v"(pending) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) pending = __hip_atomic_fetch_add(queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (MODE == READ) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc ^= d[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, 18);
+        }
+        ++trip;
+    };
+    auto take = [&]() {
+        uint32_t t;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(lds + 4u * ((trip - 1u) & 1u)) : "memory");
+        return 3u * G + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    };
+    uint32_t c0 = blk, c1 = blk + G;
+    const uint32_t c2 = blk + 2 * G;
+    if (c0 < n_chunks) {
+        u32x4 d0[U], d1[U];
+        load(d0, c0);
+        bool publish = false;
+        while (true) {
+            __builtin_amdgcn_s_barrier();
+            load(d1, c1);
+            __builtin_amdgcn_sched_barrier(0);
+            process_store(d0, c0, publish);
+            c0 = c1;
+            c1 = publish ? take() : c2;
+            publish = true;
+            if (c0 >= n_chunks) break;
+            __builtin_amdgcn_s_barrier();
+            load(d0, c1);
+            __builtin_amdgcn_sched_barrier(0);
+            process_store(d1, c0, true);
+            c0 = c1;
+            c1 = take();
+            if (c0 >= n_chunks) break;
+        }
+    }
+    if constexpr (MODE == READ) {
+        if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) sink[blk] = acc.x; // keeps the loads alive
+    }
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(queue + 1, 1u) == G - 1) {
+            __hip_atomic_store(queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+int main(int argc, char **argv)
+{
+    uint64_t n = argc > 1 ? strtoull(argv[1], nullptr, 0) : (1ull << 32);
+    uint32_t grid = argc > 2 ? (uint32_t)atoi(argv[2]) : 200u;
+    uint8_t *buf;
+    uint32_t *queue, *sink;
+    CHECK(hipMalloc(&buf, n));
+    CHECK(hipMemset(buf, 0x5A, n));
+    CHECK(hipMalloc(&queue, 64));
+    CHECK(hipMemset(queue, 0, 64));
+    CHECK(hipMalloc(&sink, 4096 * 4));
+    hipStream_t st;
+    CHECK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    const char *names[3] = {"read-only ", "write-only", "copy r+w  "};
+    std::vector<float> ms[3];
+    for (int r = 0; r < 8; ++r)
+        for (int m = 0; m < 3; ++m) {
+            CHECK(hipEventRecord(e0, st));
+            for (int k = 0; k < 2; ++k) {
+                if (m == READ) hipLaunchKernelGGL(rw_kernel<READ>, dim3(grid), dim3(BLOCK), 0, st, buf, n, queue, sink);
+                else if (m == WRITE) hipLaunchKernelGGL(rw_kernel<WRITE>, dim3(grid), dim3(BLOCK), 0, st, buf, n, queue, sink);
+                else hipLaunchKernelGGL(rw_kernel<COPY>, dim3(grid), dim3(BLOCK), 0, st, buf, n, queue, sink);
+            }
+            CHECK(hipEventRecord(e1, st));
+            CHECK(hipEventSynchronize(e1));
+            float t;
+            CHECK(hipEventElapsedTime(&t, e0, e1));
+            if (r >= 2) ms[m].push_back(t / 2);
+        }
+    CHECK(hipGetLastError());
+    printf("bytes=%llu grid=%u, work-queue schedule, 64 KiB chunks (GB/s of HBM traffic: n for read-only / write-only, 2n for copy)\n", (unsigned long long)n, grid);
+    for (int m = 0; m < 3; ++m) {
+        std::sort(ms[m].begin(), ms[m].end());
+        const double traffic = (m == COPY ? 2.0 : 1.0) * n;
+        printf("  %s  median %.4f ms -> %7.1f GB/s   best %7.1f\n", names[m], ms[m][ms[m].size() / 2], traffic / ms[m][ms[m].size() / 2] / 1e6,
+               traffic / ms[m].front() / 1e6);
+    }
+    return 0;
+}
