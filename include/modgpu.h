@@ -122,6 +122,11 @@ int modgpu_hdr_encrypt_host(uint8_t *hdr, uint64_t size, int ps4, int device);
 int modgpu_cycle_parts_host(uint8_t *const *parts, const uint64_t *sizes, int n_parts,
                             int32_t key, int n_devices);
 
+/* The same for parts that are already resident in HBM, part i on GPU devices[i] (BASELINE config 3: 8 x 4 GiB,
+ * one per GPU).  The launches are asynchronous, so the calling thread alone keeps every GPU busy; the call
+ * returns when all of them have finished.  No inter-GPU traffic. */
+int modgpu_cycle_parts_device(void *const *dev_parts, const uint64_t *sizes, const int *devices, int n_parts, int32_t key);
+
 /* ---- part files streamed through the GPU ----------------------------
  * The reference reads a part with one fread into the concatenated buffer (CArk.cpp:751) and writes
  * a slice with one fwrite (CArk.cpp:883).  These do the same transfers with the cipher applied on

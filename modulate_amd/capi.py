@@ -25,6 +25,7 @@ EXPORTS = {
     "modgpu_hdr_decrypt_host": (_int, [_vp, _u64, _int]),
     "modgpu_hdr_encrypt_host": (_int, [_vp, _u64, _int, _int]),
     "modgpu_cycle_parts_host": (_int, [ctypes.POINTER(_vp), ctypes.POINTER(_u64), _int, _i32, _int]),
+    "modgpu_cycle_parts_device": (_int, [ctypes.POINTER(_vp), ctypes.POINTER(_u64), ctypes.POINTER(_int), _int, _i32]),
     "modgpu_cycle_file": (_int, [ctypes.c_char_p, ctypes.c_char_p, _i32, _u64, _int]),
     "modgpu_cycle_file_to_host": (_int, [ctypes.c_char_p, _u64, _vp, _u64, _i32, _u64, _int]),
     "modgpu_cycle_host_to_file": (_int, [_vp, _u64, ctypes.c_char_p, _i32, _u64, _int]),
@@ -245,6 +246,15 @@ def cycle_parts_host(parts, key, n_devices=0):
     sizes = (_u64 * n)(*[p.size for p in parts])
     _check(lib().modgpu_cycle_parts_host(ptrs, sizes, n, as_int32(key), n_devices))
     return parts
+
+
+def cycle_parts_device(buffers, key):
+    """DeviceBuffers, each on its own device: every one cycled as its own stream from offset 0, all GPUs at once."""
+    n = len(buffers)
+    ptrs = (_vp * n)(*[b.ptr for b in buffers])
+    sizes = (_u64 * n)(*[b.nbytes for b in buffers])
+    devs = (_int * n)(*[b.device for b in buffers])
+    _check(lib().modgpu_cycle_parts_device(ptrs, sizes, devs, n, as_int32(key)))
 
 
 def cycle_file(src_path, dst_path, key, stream_off=0, device=-1):

@@ -438,6 +438,28 @@ int modgpu_cycle_parts_host(uint8_t *const *parts, const uint64_t *sizes, int n_
     });
 }
 
+int modgpu_cycle_parts_device(void *const *dev_parts, const uint64_t *sizes, const int *devices, int n_parts, int32_t key)
+{
+    return guarded([&]() -> int {
+        if (n_parts < 0 || (n_parts > 0 && (!dev_parts || !sizes || !devices))) return fail(MODGPU_ERR_INVALID, "bad part list");
+        int rc = MODGPU_OK;
+        int launched = 0;
+        for (; launched < n_parts && rc == MODGPU_OK; ++launched) { // every part its own Cycle from stream offset 0
+            if (devices[launched] < 0) rc = fail(MODGPU_ERR_INVALID, "a part needs an explicit device");
+            if (rc == MODGPU_OK) rc = select_device(devices[launched]);
+            if (rc == MODGPU_OK) rc = cycle_device_impl(dev_parts[launched], sizes[launched], key, 0, nullptr);
+        }
+        const std::string why = t_err;
+        for (int i = 0; i < launched; ++i) { // wait for what was started, also on the error path
+            if (devices[i] < 0 || select_device(devices[i]) != MODGPU_OK) continue;
+            hipError_t e = hipStreamSynchronize(nullptr);
+            if (e != hipSuccess && rc == MODGPU_OK) rc = fail_hip(e, "hipStreamSynchronize");
+        }
+        if (rc != MODGPU_OK && !why.empty()) t_err = why;
+        return rc;
+    });
+}
+
 int modgpu_host_alloc(void **host_ptr, uint64_t n)
 {
     return guarded([&]() -> int {

@@ -645,6 +645,20 @@ for d in range(8):
     b = M.DeviceBuffer(pt.size, device=d); b.upload(pt); b.cycle(M.KEY_PS4); b.sync()
     assert np.array_equal(b.download(), want), d
     b.free()
+# BASELINE config 3 proper: parts RESIDENT in HBM, part i on (logical) GPU i, one call drives all of them
+sizes = [(300 << 20) + 16 * i for i in range(8)]
+bufs = [M.DeviceBuffer(s, device=i) for i, s in enumerate(sizes)]
+zeros = np.zeros(max(sizes), np.uint8)
+for b in bufs:
+    b.upload(zeros[:b.nbytes])
+M.cycle_parts_device(bufs, M.KEY_PS4)
+for i, b in enumerate(bufs):
+    for off in (0, (150 << 20) + 5, b.nbytes - (1 << 20)):
+        assert np.array_equal(b.download(1 << 20, offset=off), O.keystream(M.KEY_PS4, 1 << 20, off)), (i, off)
+M.cycle_parts_device(bufs, M.KEY_PS4)
+for b in bufs:
+    assert not b.download(1 << 22, offset=b.nbytes - (1 << 22)).any() and not b.download(1 << 22).any()
+    b.free()
 try:
     M.cycle_host(pt.copy(), M.KEY_PS4, device=8)
     raise SystemExit("device 8 of 8 accepted")
