@@ -151,7 +151,8 @@ int modgpu_cycle_host_to_file(const uint8_t *host_src, uint64_t n, const char *p
  * Replaces the `new char[total]` of CArk::LoadArkData / BuildArk (CArk.cpp:738, 780) for callers
  * that will cycle the buffer: the GPU's DMA engines and kernels reach these pages directly, so
  * the host-buffer entry points above skip both staging copies for any range inside them.
- * Without a GPU the memory is ordinary (64-byte aligned) and everything still works. */
+ * Without a GPU, or if the pages cannot be locked (locked-memory limit), the memory is ordinary (64-byte
+ * aligned) and everything still works through the staged route; modgpu_host_is_pinned tells which it is. */
 int modgpu_host_alloc(void **host_ptr, uint64_t n);
 int modgpu_host_free(void *host_ptr);
 /* For callers that cannot change how their buffer is allocated: page-locks [host_ptr, host_ptr + n) where it

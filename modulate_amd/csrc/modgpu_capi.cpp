@@ -470,12 +470,13 @@ int modgpu_host_alloc(void **host_ptr, uint64_t n)
         bool pinned = false;
         if (physical_count() > 0) {
             // portable + mapped: every device's DMA engines and kernels reach these pages
-            hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped);
-            if (e != hipSuccess) return fail_hip(e, "hipHostMalloc");
-            pinned = true;
-        } else {
-            if (::posix_memalign(&p, 64, bytes) != 0) return fail(MODGPU_ERR_INVALID, "out of host memory");
+            if (hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) pinned = true;
+            else { // e.g. the locked-memory limit: ordinary memory still works, through the staged route
+                (void)hipGetLastError();
+                p = nullptr;
+            }
         }
+        if (!p && ::posix_memalign(&p, 64, bytes) != 0) return fail(MODGPU_ERR_INVALID, "out of host memory");
         {
             std::lock_guard<std::mutex> lock(g_host_mu);
             g_host_ranges.push_back({reinterpret_cast<uintptr_t>(p), bytes, pinned, false});
