@@ -18,6 +18,7 @@ EXE = os.path.join(ROOT, "modulate_amd", "bin", "modulate")
 @pytest.fixture(scope="module")
 def host(modgpu):
     assert modgpu.device_count() >= 1
+    assert modgpu.gpu_required(), "conftest must have set MODGPU_REQUIRE_GPU=1 before the library was loaded"
     from modulate_amd import host as H
     H.lib()
     H.set_flags(overwrite=True, ignore_new=True, pack_all=False, verbose=False)
