@@ -28,15 +28,26 @@
  * kernel and NOTHING ELSE: without a usable HIP device they fail with MODGPU_ERR_NO_DEVICE /
  * MODGPU_ERR_HIP.  The two exceptions are named for what they are:
  *     modgpu_cycle_scalar_host   the library's own host loop (never the GPU)
- *     modgpu_cycle_auto_host     the reference's "Cycle cannot fail" contract: GPU, and the host
- *                                loop only when no GPU is usable
+ *     modgpu_cycle_auto_host     the reference's "Cycle cannot fail" contract and its size dispatch: the
+ *                                host loop for buffers below MODGPU_MIN_GPU_BYTES (header-sized: a kernel
+ *                                launch costs more than the arithmetic) or when no GPU is usable, else the GPU
  * modgpu_path_stats() counts calls and bytes per engine, and MODGPU_REQUIRE_GPU=1 in the environment
  * forbids the host loop altogether (both entry points then fail with MODGPU_ERR_FORBIDDEN instead of
  * computing), so a test-suite or benchmark can prove which engine produced its bytes.
  *
  * Threading: callable concurrently from any number of host threads.  `device` selects the GPU
  * per call (-1 = the calling thread's current HIP device); no global "current device" is
- * relied on.  Host-buffer calls to the same device serialise on that device's staging context.
+ * relied on, and a call made with an explicit device leaves the calling thread's current HIP
+ * device as it found it.  Host-buffer calls to the same device serialise on that device's staging context.
+ *
+ * Environment (each read once, when first needed):
+ *     MODGPU_REQUIRE_GPU=1       no host loop anywhere (see above)
+ *     MODGPU_MIN_GPU_BYTES=n     modgpu_cycle_auto_host's size threshold (default 131072; 0 = always the GPU)
+ *     MODGPU_HOST_ISA=name       host-loop body: generic | avx2 | avx512 (default: the best the CPU runs)
+ *     MODGPU_HOST_THREADS=n      most host threads one host-loop call may use (default min(cores, 32))
+ *     MODGPU_DEVICE_ALIAS=n      see modgpu_device_count
+ *     MODGPU_HOST_PIPES / _CHUNK_MB / _ZEROCOPY_KB / _RING   staging pipeline of the host-buffer routes
+ *     MODGPU_NUMA=0              do not place host memory and worker threads next to their GPU
  */
 #ifndef MODGPU_H
 #define MODGPU_H
@@ -65,7 +76,7 @@ extern "C" {
 #define MODGPU_KEY_PS4 0x90cfc0abu
 
 /* ABI version of this header (bumped on any signature change). */
-#define MODGPU_ABI_VERSION 3
+#define MODGPU_ABI_VERSION 4
 int modgpu_abi_version(void);
 
 /* Number of HIP devices this library addresses (0 if none / runtime unusable).  Normally the
@@ -83,9 +94,10 @@ const char *modgpu_last_error(void);
  * that is already device-resident.  `dev_buf` may have any byte alignment (the reference's
  * callers pass buf+4).  Asynchronous on `hip_stream` (a hipStream_t; NULL = the device's
  * null stream); the caller synchronises.  This is the entry point the roofline is measured on.
- * Allocation-free and capturable into a hipGraph; a captured launch of a large buffer carries its own
- * scheduling scratch word, so one captured launch must not run twice at the same time (replaying it
- * back to back, or capturing it twice, is fine). */
+ * Allocation-free and capturable into a hipGraph.  Any number of launches may be in flight at once, on any
+ * streams, eager or replayed from graphs: the scheduling scratch of a large launch is never shared between two
+ * launches that could overlap (a captured launch owns its scratch for good; an eager one gets scratch whose
+ * previous user has finished, or a launch shape that needs none). */
 int modgpu_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off,
                         int device, void *hip_stream);
 
@@ -102,10 +114,12 @@ int modgpu_cycle_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t strea
  * product code for hosts without a GPU -- it shares nothing with the test oracle under oracle/. */
 int modgpu_cycle_scalar_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off);
 
-/* What CEncryptionCycler::Cycle binds to.  The reference's Cycle returns void and cannot fail
- * (CEncryptionCycler.cpp:4-14), so: modgpu_cycle_host when a GPU is usable; when none is visible,
- * or the GPU attempt fails before it has touched host_buf, modgpu_cycle_scalar_host.  With
- * MODGPU_REQUIRE_GPU=1 there is no second engine and the GPU error is returned. */
+/* What CEncryptionCycler::Cycle binds to (`if (n < threshold || !gpu_ok) cpu_loop(); else ...`).
+ * n < MODGPU_MIN_GPU_BYTES -- the headers the reference's three call sites pass -- is served by the host loop,
+ * which finishes such a buffer before a kernel launch would have returned; larger buffers by modgpu_cycle_host.
+ * The reference's Cycle returns void and cannot fail (CEncryptionCycler.cpp:4-14), so when no GPU is visible,
+ * or the GPU attempt fails before it has touched host_buf, the host loop finishes the call.  With
+ * MODGPU_REQUIRE_GPU=1 there is no second engine: every size runs on the kernel and a GPU error is returned. */
 int modgpu_cycle_auto_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, int device);
 
 /* Header framing of CArk::Load (CArk.cpp:328-339) and Decode (Modulate.cpp:475-486):
@@ -155,6 +169,18 @@ int modgpu_cycle_host_to_file(const uint8_t *host_src, uint64_t n, const char *p
  * aligned) and everything still works through the staged route; modgpu_host_is_pinned tells which it is. */
 int modgpu_host_alloc(void **host_ptr, uint64_t n);
 int modgpu_host_free(void *host_ptr);
+/* The same, placed for a multi-socket node: the pages are bound to the NUMA node the GPU hangs off
+ * (/sys/bus/pci/devices/<bdf>/numa_node; mbind, preferred policy) before they are locked, so the bytes that
+ * cross PCIe to that GPU come from its own socket's DRAM.  modgpu_host_alloc_parts makes ONE contiguous buffer
+ * for a list of parts laid end to end -- the concatenated buffer of CArk::LoadArkData / BuildArk (CArk.cpp:738,
+ * 780) -- with part i's pages next to GPU i mod n_devices, the GPU modgpu_cycle_parts_host sends it to
+ * (n_devices <= 0: all).  Where the topology is unknown, MODGPU_NUMA=0, or there is one node, both are
+ * modgpu_host_alloc.  Free with modgpu_host_free.  Worker threads of the host-buffer routes run on their GPU's
+ * node as well.  Placement is best effort and changes no result. */
+int modgpu_host_alloc_near(void **host_ptr, uint64_t n, int device);
+int modgpu_host_alloc_parts(void **host_ptr, const uint64_t *sizes, int n_parts, int n_devices);
+/* NUMA node of the GPU behind `device`, -1 if unknown or placement is off. */
+int modgpu_device_numa_node(int device);
 /* For callers that cannot change how their buffer is allocated: page-locks [host_ptr, host_ptr + n) where it
  * lies (hipHostRegister) so that later cycles of ranges inside it take the no-copy route.  Pinning costs
  * about as much as one staged pass over the buffer, so it pays from the second cycle on.  Unregister
@@ -173,12 +199,17 @@ typedef struct modgpu_path_stats {
     uint64_t scalar_bytes;
     uint64_t staged_bytes;   /* of gpu_bytes: went through a pageable<->pinned memcpy            */
     uint64_t direct_bytes;   /* of gpu_bytes: DMA'd or read straight from the caller's pinned pages */
-    uint64_t auto_fallbacks; /* modgpu_cycle_auto_host calls that ended on the host loop         */
+    uint64_t auto_fallbacks; /* modgpu_cycle_auto_host calls that ended on the host loop because the GPU could not serve them */
+    uint64_t auto_small;     /* modgpu_cycle_auto_host calls served by the host loop because n < MODGPU_MIN_GPU_BYTES */
 } modgpu_path_stats_t;
 /* Process-wide counters since load (or the last reset).  reset != 0 zeroes them after the read. */
 int modgpu_path_stats(modgpu_path_stats_t *out, int reset);
 /* 1 if MODGPU_REQUIRE_GPU=1 was set when the library was loaded. */
 int modgpu_gpu_required(void);
+/* modgpu_cycle_auto_host's size threshold as latched from MODGPU_MIN_GPU_BYTES. */
+uint64_t modgpu_min_gpu_bytes(void);
+/* The host-loop body this process uses: "generic", "avx2" or "avx512".  Static storage. */
+const char *modgpu_host_loop_isa(void);
 
 /* ---- thin device-memory helpers (bench / tests / callers that keep parts resident) --- */
 int modgpu_alloc(void **dev_ptr, uint64_t n, int device);

@@ -1,11 +1,17 @@
 /*
- * modgpu_testing.h -- measurement and test hooks of libmodgpu.so.
+ * modgpu_testing.h -- measurement and test hooks.
  *
  * NOT part of the drop-in boundary (that is include/modgpu.h, the only header an integrator
- * needs).  bench.py, tools/ and tests/ use these to time launches on the launch stream, to learn
- * which kernel instantiation a launch used, and to drive the streaming kernel through odd trip
- * counts on small buffers.  Nothing here changes results: every hook either reports or picks
- * between launch shapes that compute the same bytes.
+ * needs).  Two groups:
+ *
+ *   reporting   in libmodgpu.so.  They time launches on the launch stream and say which kernel
+ *               instantiation a launch used, what the library latched from the environment, and what
+ *               the work-queue bookkeeping did.  They change nothing.
+ *   modgpu_debug_*   ONLY in the testing flavour, libmodgpu_testing.so (the same sources built with
+ *               -DMODGPU_TESTING_HOOKS).  They force launch shapes, routes, the size of the ticket ring
+ *               and failures, process-wide, so that tests can drive every branch on small buffers.  The
+ *               shipped library does not contain them (`nm -D libmodgpu.so | grep debug_` is empty):
+ *               nothing in a production process can change how it launches or make a call fail.
  */
 #ifndef MODGPU_TESTING_H
 #define MODGPU_TESTING_H
@@ -34,6 +40,39 @@ typedef struct modgpu_launch_info {
 } modgpu_launch_info_t;
 int modgpu_last_launch(modgpu_launch_info_t *out);
 
+/* The host-path tunables as the library latched them at load (after clamping): out[0] = pipelines
+ * (MODGPU_HOST_PIPES), out[1] = largest slot in bytes (MODGPU_HOST_CHUNK_MB), out[2] = largest buffer cycled in
+ * one pinned slot without chunking (MODGPU_HOST_ZEROCOPY_KB, never above out[1]), out[3] = DMA ring depth. */
+void modgpu_host_tunables(uint64_t out[4]);
+
+/* modgpu_cycle_scalar_host with one named body ("generic", "avx2", "avx512"); MODGPU_ERR_INVALID if this CPU
+ * does not run it.  Lets the tests compare every body with the oracle on one machine. */
+int modgpu_cycle_scalar_host_isa(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, const char *isa);
+
+/* The topology reader behind modgpu_host_alloc_near, pointed at any sysfs tree (tests hand it a fake one):
+ * *node = NUMA node of PCI function `bdf` (-1 unknown), cpus[0..return) = that node's CPUs (at most max_cpus). */
+int modgpu_numa_probe(const char *sysfs_root, const char *bdf, int *node, int *cpus, int max_cpus);
+
+/* Work-queue bookkeeping since load: out[0] = eager launches that got a ring line, out[1] = eager launches that
+ * found every line busy and took the static shape, out[2] = captured launches that got a line of their own,
+ * out[3] = captured launches that found the pool empty (static shape). */
+void modgpu_queue_stats(uint64_t out[4]);
+
+/* Identity of the device code this library carries: hex SHA-256 over the kernel sources it was
+ * built from (cycle_kernel_impl.h, cycle_kernel.hip, cycle_kernel.h, lcg.h), fixed at build time.
+ * profiles/pmc_summary.json records it so that counter figures are never replayed for other code. */
+const char *modgpu_kernel_source_hash(void);
+
+/* 1 in libmodgpu_testing.so, 0 in libmodgpu.so. */
+int modgpu_testing_hooks(void);
+
+/* ---- below: libmodgpu_testing.so only ------------------------------------------------------------------ */
+
+/* Eager work-queue launches draw their ticket pair from the first `lines` lines of the ring (1..256; 0 = all
+ * 256).  With one line every second launch in flight finds the ring busy: the collision the gating exists for
+ * becomes certain instead of a 1-in-256 event. */
+void modgpu_debug_set_queue_ring(uint32_t lines);
+
 /* Forces the launch shape of every later launch in this process (-1 = by size, the default) and
  * caps the grid (0 = no cap).  Lets the parity tests run the streaming kernels with 1, 2, odd and
  * even trip counts and ragged ends on buffers of a few MiB. */
@@ -54,15 +93,6 @@ void modgpu_debug_set_staged_mode(int mode);
  * ("a GPU is visible but the attempt failed") on a machine whose GPU works. */
 void modgpu_debug_inject_failures(int count);
 
-/* The host-path tunables as the library latched them at load (after clamping): out[0] = pipelines
- * (MODGPU_HOST_PIPES), out[1] = largest slot in bytes (MODGPU_HOST_CHUNK_MB), out[2] = largest buffer cycled in
- * one pinned slot without chunking (MODGPU_HOST_ZEROCOPY_KB, never above out[1]), out[3] = DMA ring depth. */
-void modgpu_debug_host_tunables(uint64_t out[4]);
-
-/* Identity of the device code this library carries: hex SHA-256 over the kernel sources it was
- * built from (cycle_kernel_impl.h, cycle_kernel.hip, cycle_kernel.h, lcg.h), fixed at build time.
- * profiles/pmc_summary.json records it so that counter figures are never replayed for other code. */
-const char *modgpu_kernel_source_hash(void);
 
 #ifdef __cplusplus
 }

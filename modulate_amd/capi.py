@@ -1,7 +1,14 @@
 """ctypes binding over libmodgpu.so -- every call goes through the C ABI of include/modgpu.h.
 
 Nothing is computed in Python: if the library is missing or a call fails, ModGpuError is raised.
+
+Two flavours of the library exist (modulate_amd/csrc/Makefile): the shipped libmodgpu.so, which is what every
+call here uses by default, and libmodgpu_testing.so -- the same sources and device code plus the
+modgpu_debug_* hooks of include/modgpu_testing.h.  `with testing_flavour():` routes the calls made inside
+the block to the testing flavour (both can be loaded in one process); the debug_* functions refuse to run
+outside such a block, because the shipped library has no such hooks.
 """
+import contextlib
 import ctypes
 import os
 
@@ -45,13 +52,18 @@ EXPORTS = {
     "modgpu_host_unregister": (_int, [_vp]),
     "modgpu_path_stats": (_int, [_vp, _int]),
     "modgpu_gpu_required": (_int, []),
+    "modgpu_min_gpu_bytes": (_u64, []),
+    "modgpu_host_loop_isa": (ctypes.c_char_p, []),
+    "modgpu_host_alloc_near": (_int, [ctypes.POINTER(_vp), _u64, _int]),
+    "modgpu_host_alloc_parts": (_int, [ctypes.POINTER(_vp), ctypes.POINTER(_u64), _int, _int]),
+    "modgpu_device_numa_node": (_int, [_int]),
 }
 
 
 class PathStats(ctypes.Structure):
     """modgpu_path_stats_t (include/modgpu.h)."""
     _fields_ = [(k, _u64) for k in ("gpu_calls", "gpu_bytes", "gpu_launches", "scalar_calls", "scalar_bytes",
-                                    "staged_bytes", "direct_bytes", "auto_fallbacks")]
+                                    "staged_bytes", "direct_bytes", "auto_fallbacks", "auto_small")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -63,15 +75,23 @@ class LaunchInfo(ctypes.Structure):
                 ("chunk_bytes", ctypes.c_uint32), ("bytes", _u64)]
 
 
-# every symbol include/modgpu_testing.h declares (measurement / test hooks, not the drop-in boundary)
+# include/modgpu_testing.h, reporting group: in both flavours (measurement, not the drop-in boundary)
 TESTING_EXPORTS = {
     "modgpu_time_cycle_device": (_int, [_vp, _u64, _i32, _u64, _int, _vp, _int, ctypes.POINTER(ctypes.c_float)]),
     "modgpu_last_launch": (_int, [ctypes.POINTER(LaunchInfo)]),
+    "modgpu_kernel_source_hash": (ctypes.c_char_p, []),
+    "modgpu_host_tunables": (None, [ctypes.POINTER(_u64)]),
+    "modgpu_cycle_scalar_host_isa": (_int, [_vp, _u64, _i32, _u64, ctypes.c_char_p]),
+    "modgpu_queue_stats": (None, [ctypes.POINTER(_u64)]),
+    "modgpu_testing_hooks": (_int, []),
+    "modgpu_numa_probe": (_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_int), ctypes.POINTER(_int), _int]),
+}
+# include/modgpu_testing.h, modgpu_debug_* group: ONLY in libmodgpu_testing.so
+DEBUG_EXPORTS = {
     "modgpu_debug_set_launch": (None, [_int, ctypes.c_uint32]),
     "modgpu_debug_set_pinned_mode": (None, [_int]),
     "modgpu_debug_set_staged_mode": (None, [_int]),
-    "modgpu_kernel_source_hash": (ctypes.c_char_p, []),
-    "modgpu_debug_host_tunables": (None, [ctypes.POINTER(_u64)]),
+    "modgpu_debug_set_queue_ring": (None, [ctypes.c_uint32]),
     "modgpu_debug_inject_failures": (None, [_int]),
 }
 
@@ -82,27 +102,65 @@ class ModGpuError(RuntimeError):
         self.code = code
 
 
-def lib_path():
-    return os.path.join(_HERE, "libmodgpu.so")
+FLAVOURS = {"shipped": "libmodgpu.so", "testing": "libmodgpu_testing.so"}
 
 
-_lib = None
+def lib_path(flavour="shipped"):
+    return os.path.join(_HERE, FLAVOURS[flavour])
 
 
-def lib():
-    """The loaded libmodgpu.so.  Raises if it was not built (python __graft_entry__.py build)."""
-    global _lib
-    if _lib is None:
-        path = lib_path()
+_libs = {}
+_active = "shipped"
+
+
+def _load(flavour):
+    if flavour not in _libs:
+        path = lib_path(flavour)
         if not os.path.exists(path):
             raise ModGpuError(-1, f"{path} not built: run `make -C modulate_amd/csrc` (the Python package has no implementation of its own)")
         L = ctypes.CDLL(path)
-        for name, (res, args) in list(EXPORTS.items()) + list(TESTING_EXPORTS.items()):
+        table = list(EXPORTS.items()) + list(TESTING_EXPORTS.items()) + (list(DEBUG_EXPORTS.items()) if flavour == "testing" else [])
+        for name, (res, args) in table:
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = L
-    return _lib
+        _libs[flavour] = L
+    return _libs[flavour]
+
+
+def lib():
+    """The library calls go to: the shipped libmodgpu.so, or libmodgpu_testing.so inside `testing_flavour()`.
+    Raises if it was not built (python __graft_entry__.py build)."""
+    return _load(_active)
+
+
+def active_flavour():
+    return _active
+
+
+@contextlib.contextmanager
+def testing_flavour():
+    """Calls made inside the block go to libmodgpu_testing.so (the flavour that has the modgpu_debug_* hooks).
+    Buffers created inside keep using it after the block (they remember their library)."""
+    global _active
+    prev, _active = _active, "testing"
+    try:
+        yield _load("testing")
+    finally:
+        _active = prev
+
+
+def use_testing_flavour():
+    """For tools/: switch this process to libmodgpu_testing.so for good."""
+    global _active
+    _active = "testing"
+    return _load("testing")
+
+
+def _debug_lib():
+    if _active != "testing":
+        raise ModGpuError(-1, "modgpu_debug_* hooks exist only in libmodgpu_testing.so: call inside `with testing_flavour():`")
+    return _load("testing")
 
 
 def as_int32(key):
@@ -166,28 +224,70 @@ SHAPES = {None: -1, "auto": -1, "small": 0, "large": 1, "queue": 2}
 def debug_set_launch(shape=None, grid_cap=0):
     """Test hook: force the launch shape ("small" / "large" = streaming, static chunk map / "queue" = streaming,
     work queue / None = by size) and cap the grid."""
-    lib().modgpu_debug_set_launch(SHAPES[shape], grid_cap or 0)
+    _debug_lib().modgpu_debug_set_launch(SHAPES[shape], grid_cap or 0)
 
 
 def debug_set_pinned_mode(mode=0):
     """Test hook: 0 default, 1 DMA pipeline, 2 kernel over PCIe, for pinned caller buffers."""
-    lib().modgpu_debug_set_pinned_mode(mode)
+    _debug_lib().modgpu_debug_set_pinned_mode(mode)
 
 
 def debug_set_staged_mode(mode=0):
     """Test hook: 0 default, 1 DMA, 2 kernel over PCIe on the pinned slot, for staged (pageable / file) chunks."""
-    lib().modgpu_debug_set_staged_mode(mode)
+    _debug_lib().modgpu_debug_set_staged_mode(mode)
 
 
 def debug_inject_failures(count):
     """Test hook: the next `count` host-buffer / file calls fail with MODGPU_ERR_HIP before touching anything."""
-    lib().modgpu_debug_inject_failures(count)
+    _debug_lib().modgpu_debug_inject_failures(count)
+
+
+def debug_set_queue_ring(lines=0):
+    """Test hook: eager work-queue launches draw ticket pairs from the first `lines` ring lines only (0 = all 256)."""
+    _debug_lib().modgpu_debug_set_queue_ring(lines)
+
+
+def queue_stats():
+    """Work-queue bookkeeping since load (include/modgpu_testing.h: modgpu_queue_stats)."""
+    out = (_u64 * 4)()
+    lib().modgpu_queue_stats(out)
+    return {"eager": int(out[0]), "busy_fallbacks": int(out[1]), "graph": int(out[2]), "graph_pool_empty": int(out[3])}
+
+
+def testing_hooks():
+    return bool(lib().modgpu_testing_hooks())
+
+
+def min_gpu_bytes():
+    return int(lib().modgpu_min_gpu_bytes())
+
+
+def host_loop_isa():
+    return lib().modgpu_host_loop_isa().decode()
+
+
+def cycle_scalar_host_isa(buf, key, isa, stream_off=0):
+    """The library's host loop with one named body ("generic" / "avx2" / "avx512")."""
+    _check(lib().modgpu_cycle_scalar_host_isa(_host_ptr(buf), buf.size, as_int32(key), stream_off, isa.encode()))
+    return buf
+
+
+def device_numa_node(device):
+    return lib().modgpu_device_numa_node(device)
+
+
+def numa_probe(sysfs_root, bdf, max_cpus=4096):
+    """(node, cpus) as the library reads them from a sysfs tree (tests hand it a fake one)."""
+    node = _int(-1)
+    cpus = (_int * max_cpus)()
+    n = lib().modgpu_numa_probe(os.fsencode(sysfs_root), bdf.encode(), ctypes.byref(node), cpus, max_cpus)
+    return node.value, list(cpus[:max(n, 0)])
 
 
 def host_tunables():
     """The host-path tunables as latched (and clamped) at library load."""
     out = (_u64 * 4)()
-    lib().modgpu_debug_host_tunables(out)
+    lib().modgpu_host_tunables(out)
     return {"pipes": int(out[0]), "chunk_bytes": int(out[1]), "zerocopy_max_bytes": int(out[2]), "ring": int(out[3])}
 
 
@@ -198,20 +298,30 @@ def kernel_source_hash():
 class PinnedBuffer:
     """Host memory from modgpu_host_alloc, viewed as a numpy uint8 array (`.array`)."""
 
-    def __init__(self, nbytes):
+    def __init__(self, nbytes, near_device=None, parts=None, n_devices=0):
+        """near_device: place the pages next to that GPU (modgpu_host_alloc_near); parts: list of part sizes laid end
+        to end, part i next to GPU i mod n_devices (modgpu_host_alloc_parts; nbytes must be their sum)."""
         p = _vp()
-        _check(lib().modgpu_host_alloc(ctypes.byref(p), nbytes))
+        self._lib = lib()
+        if parts is not None:
+            assert sum(parts) == nbytes
+            sizes = (_u64 * len(parts))(*parts)
+            _check(self._lib.modgpu_host_alloc_parts(ctypes.byref(p), sizes, len(parts), n_devices))
+        elif near_device is not None:
+            _check(self._lib.modgpu_host_alloc_near(ctypes.byref(p), nbytes, near_device))
+        else:
+            _check(self._lib.modgpu_host_alloc(ctypes.byref(p), nbytes))
         self.ptr, self.nbytes = p.value, nbytes
         self.array = np.ctypeslib.as_array(ctypes.cast(self.ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(max(nbytes, 1),))[:nbytes]
 
     @property
     def pinned(self):
-        return bool(lib().modgpu_host_is_pinned(_vp(self.ptr), self.nbytes))
+        return bool(self._lib.modgpu_host_is_pinned(_vp(self.ptr), self.nbytes))
 
     def free(self):
         if self.ptr:
             self.array = None
-            _check(lib().modgpu_host_free(_vp(self.ptr)))
+            _check(self._lib.modgpu_host_free(_vp(self.ptr)))
             self.ptr = None
 
     def __del__(self):
@@ -307,18 +417,19 @@ class DeviceBuffer:
     def __init__(self, nbytes, device=-1):
         self.nbytes, self.device = nbytes, device
         p = _vp()
-        _check(lib().modgpu_alloc(ctypes.byref(p), nbytes, device))
+        self._lib = lib()
+        _check(self._lib.modgpu_alloc(ctypes.byref(p), nbytes, device))
         self.ptr = p.value
 
     def upload(self, host, offset=0):
         host = np.ascontiguousarray(host, dtype=np.uint8)
         assert offset + host.size <= self.nbytes
-        _check(lib().modgpu_h2d(_vp(self.ptr + offset), _vp(host.ctypes.data), host.size, self.device))
+        _check(self._lib.modgpu_h2d(_vp(self.ptr + offset), _vp(host.ctypes.data), host.size, self.device))
 
     def download(self, n=None, offset=0):
         n = self.nbytes - offset if n is None else n
         out = np.empty(n, dtype=np.uint8)
-        _check(lib().modgpu_d2h(_vp(out.ctypes.data), _vp(self.ptr + offset), n, self.device))
+        _check(self._lib.modgpu_d2h(_vp(out.ctypes.data), _vp(self.ptr + offset), n, self.device))
         return out
 
     def cycle(self, key, n=None, offset=0, stream_off=0, stream=None):
@@ -327,11 +438,11 @@ class DeviceBuffer:
         cycle_device(self.ptr + offset, n, key, stream_off, self.device, stream)
 
     def sync(self, stream=None):
-        _check(lib().modgpu_sync(self.device, _vp(stream or 0)))
+        _check(self._lib.modgpu_sync(self.device, _vp(stream or 0)))
 
     def free(self):
         if self.ptr:
-            _check(lib().modgpu_free(_vp(self.ptr), self.device))
+            _check(self._lib.modgpu_free(_vp(self.ptr), self.device))
             self.ptr = None
 
     def __del__(self):

@@ -19,6 +19,8 @@ struct CycleArgs {
     uint32_t base_head;  // state of the buffer's first byte
     uint32_t base_tail;  // state of the first tail byte
     uint32_t *queue;     // work-queue shape only: {ticket counter, workgroups done}, both 0 at launch and 0 again at exit
+    uint32_t *queue_done; // work-queue shape: host-visible word that receives queue_seq once the pair is clean again (the host
+    uint32_t queue_seq;   // hands a pair out again only after it has seen that); nullptr: nobody waits for this pair
     uint64_t *trace;     // nullptr in the product.  tools/tune_cycle's TRACE instantiation writes per-workgroup
                          // timestamps here (wall_clock64, 100 MHz): [blk*32+0] start, [+1+k] end of trip k, [+31] XCC id
 };

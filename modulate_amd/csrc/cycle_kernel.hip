@@ -10,15 +10,22 @@
 //   state of byte j of the word      S_j = S * a^j mod m,  j = 1..15                  (independent)
 //   keystream byte                   ks  = low8(S_j) ^ 0xFF
 //
-// Integer only: this is HBM-bound byte work, no MFMA, no LDS.  One byte costs two v_mad_u64_u32 (the
-// product, then the Mersenne fold 2^31 == 1 mod m as a second multiply-add), a shift and one SDWA
-// add that canonicalises and packs it; "^0xFF" and the data XOR are one v_xnor per dword.
+// Integer only: this is HBM-bound byte work, no MFMA; LDS holds nothing but an 8-byte ticket mailbox.  One byte costs
+// two v_mad_u64_u32 (the product, then the Mersenne fold 2^31 == 1 mod m as a second multiply-add), a shift and
+// one SDWA add that canonicalises and packs it; "^0xFF" and the data XOR are one v_xnor per dword.
 //
-// Two launch shapes (cycle_kernel.h).  The streaming one is what the roofline is measured on:
-// one persistent 1024-thread workgroup per CU, 128 KiB chunks on absolute 128 KiB-aligned
-// addresses, the next chunk's eight loads in flight while this one is computed, loads and stores
-// issued as workgroup-synchronous bursts (nt loads, sc1 stores).  DESIGN.md 3-4 has the measurements
-// behind each of these choices.
+// Three launch shapes (cycle_kernel.h):
+//   queue   what the roofline is measured on (buffers > 256 MiB): persistent 1024-thread workgroups, 25 per 32 CUs,
+//           64 KiB chunks on absolute 64 KiB-aligned addresses handed out by a ticket counter (a static prefix of
+//           three, then tickets fetched a trip ahead), so fast and slow XCDs finish together; the next chunk's
+//           four loads are in flight while this one is computed; loads and stores are issued as
+//           workgroup-synchronous bursts (nt loads, sc1+nt stores).  The {ticket, done} pair is cleaned by the last
+//           workgroup out, which then signs off in a host-visible word so the host never hands a pair to two
+//           launches that could overlap (modgpu_capi.cpp: queue_pair).
+//   large   the same bursts with the static chunk map (b, b+G, ...), 128 KiB chunks, one workgroup per CU: what a
+//           launch takes when no ticket pair is free, or beyond 2^24 chunks.
+//   small   256 threads x one word, no pipeline: headers ... 256 MiB, and page-locked host memory across PCIe.
+// DESIGN.md 3-4 has the measurements behind each of these choices.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 

@@ -322,7 +322,8 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
 // (in front of that trip's store burst, so waiting for it later never waits for those stores), publishes the
 // value through an LDS word (two, used alternately) before the NEXT trip's second barrier, and every wave reads it
 // after that barrier.  a.queue[0] is the ticket counter, a.queue[1] counts workgroups that are done; the last one out
-// zeroes both, so the pair is clean for the next launch without a memset.
+// zeroes both, so the pair is clean for the next launch without a memset, and then writes a.queue_seq to the host-visible
+// word a.queue_done: the host hands a pair to a new launch only after its previous user has signed off there.
 // DEPTH = chunks of loads a workgroup keeps in flight ahead of the one it computes (1 = ping-pong as above)
 // MODE  = MODE_FULL in the product; MODE_COPY (tools/tune_cycle) is the same loop without the keystream: the
 //         memory system's ceiling for this access pattern
@@ -477,12 +478,17 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
             }
         }
     }
-    // leave: this workgroup's ticket atomics have all returned; the last workgroup out resets the pair
+    // leave: this workgroup's ticket atomics have all returned; the last workgroup out resets the pair and then
+    // tells the host (a word in host-coherent memory) that the pair may be handed to another launch
     if (tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (atomicAdd(a.queue + 1, 1u) == G - 1) {
             __hip_atomic_store(a.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.queue_done) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // both zeroes have been performed device-wide
+                __hip_atomic_store(a.queue_done, a.queue_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }

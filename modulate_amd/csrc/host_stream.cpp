@@ -37,9 +37,24 @@
 
 namespace modgpu {
 
+// Route selectors and failure injection exist only in the testing flavour of the library
+// (libmodgpu_testing.so, -DMODGPU_TESTING_HOOKS); the shipped one always takes the default routes.
+#ifdef MODGPU_TESTING_HOOKS
 std::atomic<int> g_pinned_mode{0};
 std::atomic<int> g_staged_mode{0};
 std::atomic<int> g_inject_failures{0}; // modgpu_debug_inject_failures
+namespace {
+int pinned_mode() { return g_pinned_mode.load(std::memory_order_relaxed); }
+int staged_mode() { return g_staged_mode.load(std::memory_order_relaxed); }
+bool injected_failure() { return g_inject_failures.load(std::memory_order_relaxed) > 0 && g_inject_failures.fetch_sub(1) > 0; }
+} // namespace
+#else
+namespace {
+constexpr int pinned_mode() { return 0; }
+constexpr int staged_mode() { return 0; }
+constexpr bool injected_failure() { return false; }
+} // namespace
+#endif
 
 namespace {
 
@@ -209,10 +224,10 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     if (touched) *touched = false;
     if (n == 0) return MODGPU_OK;
     int dev = 0;
-    int rc = resolve_device(device, &dev);
+    DeviceScope scope(device); // the calling thread gets its own current device back
+    int rc = scope.rc ? scope.rc : resolve_device(device, &dev);
     if (rc) return rc;
-    if (g_inject_failures.load(std::memory_order_relaxed) > 0 && g_inject_failures.fetch_sub(1) > 0)
-        return fail(MODGPU_ERR_HIP, "injected failure (modgpu_debug_inject_failures)");
+    if (injected_failure()) return fail(MODGPU_ERR_HIP, "injected failure (modgpu_debug_inject_failures)");
     // keys == 0 mod m give the identity: nothing to do in place, a plain copy otherwise
     const bool identity = (int64_t)key % 0x7FFFFFFFll == 0;
     const bool in_place = src.mem && src.mem == dst.mem;
@@ -234,7 +249,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     // kernel reads and writes the pinned pages across PCIe itself (they are device-visible).
     // (default for pinned memory: measured 50 GB/s of payload against 26-29 for the DMA ring below and
     //  30 for the staged route, profiles/r02_sweep_pinned_routes.txt; mode 1 keeps the DMA ring selectable)
-    const int mode = g_pinned_mode.load(std::memory_order_relaxed);
+    const int mode = pinned_mode();
     if (in_place && src_direct && !identity && (n <= kZeroCopyMax || mode != 1)) {
         rc = staging_reserve(s, 0, 1, 0, false, false);
         if (rc) return rc;
@@ -272,7 +287,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     chunk = std::min<uint64_t>(chunk, kChunk);
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
     Job job{src, dst, n, chunk, key, stream_off};
-    job.slot_kernel = !src_direct && !dst_direct && g_staged_mode.load(std::memory_order_relaxed) != 1;
+    job.slot_kernel = !src_direct && !dst_direct && staged_mode() != 1;
     int pipes, ring;
     if (all_direct && src.mem && dst.mem) { // no host work at all: one thread keeps a ring of slots busy
         pipes = 1;
@@ -291,7 +306,8 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
         std::vector<std::string> errs((size_t)pipes);
         std::vector<std::thread> workers;
         const int phys = physical_of(dev);
-        auto body = [&](int p) {
+        auto body = [&](int p, bool own_thread) {
+            if (own_thread) run_near_device(dev); // a staging worker's memcpys run on the socket its GPU hangs off
             if (hipSetDevice(phys) != hipSuccess) { // HIP's current device is per thread
                 rcs[p] = MODGPU_ERR_HIP;
                 errs[p] = "hipSetDevice in staging worker";
@@ -302,11 +318,11 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
         };
         int started = 1; // pipeline 0 runs on the calling thread
         try {
-            for (int p = 1; p < pipes; ++p, ++started) workers.emplace_back(body, p);
+            for (int p = 1; p < pipes; ++p, ++started) workers.emplace_back(body, p, true);
         } catch (...) { // thread limit: the pipelines that did not get a thread run here, one after another
         }
-        body(0);
-        for (int p = started; p < pipes; ++p) body(p);
+        body(0, false);
+        for (int p = started; p < pipes; ++p) body(p, false);
         for (auto &w : workers) w.join();
         for (int p = 0; p < pipes && rc == MODGPU_OK; ++p)
             if (rcs[p]) {
@@ -333,9 +349,11 @@ struct Fd { // closes on scope exit
 
 extern "C" {
 
+#ifdef MODGPU_TESTING_HOOKS
 void modgpu_debug_inject_failures(int count) { g_inject_failures.store(count > 0 ? count : 0); }
+#endif
 
-void modgpu_debug_host_tunables(uint64_t out[4])
+void modgpu_host_tunables(uint64_t out[4])
 {
     out[0] = (uint64_t)kPipes;
     out[1] = kChunk;

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cerrno>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +19,7 @@
 #include "cycle_kernel.h"
 #include "lcg.h"
 #include "modgpu_internal.h"
+#include "numa_place.h"
 #include "scalar_path.h"
 
 #ifndef MODGPU_KERNEL_SOURCE_HASH
@@ -48,6 +50,22 @@ int fail_io(const char *what)
 {
     t_err = std::string(what) + ": " + std::strerror(errno);
     return MODGPU_ERR_IO;
+}
+
+// MODGPU_MIN_GPU_BYTES (read once): modgpu_cycle_auto_host serves buffers shorter than this with the host loop.
+// Default: the measured crossover on the MI355X node (profiles/r03_small_call_crossover.txt) -- a kernel launch
+// plus the wait for it costs ~14 us before the first byte moves, the host loop does a header in less.
+constexpr uint64_t kMinGpuBytesDefault = 128ull << 10;
+uint64_t min_gpu_bytes()
+{
+    static const uint64_t v = [] {
+        const char *e = std::getenv("MODGPU_MIN_GPU_BYTES");
+        if (!e || !*e) return kMinGpuBytesDefault;
+        char *end = nullptr;
+        unsigned long long x = std::strtoull(e, &end, 0);
+        return end && end != e ? (uint64_t)x : kMinGpuBytesDefault;
+    }();
+    return v;
 }
 
 bool gpu_required()
@@ -114,6 +132,49 @@ int resolve_device(int device, int *out)
     return MODGPU_OK;
 }
 
+// NUMA node the GPU behind a logical device hangs off (-1: unknown, or placement switched off by MODGPU_NUMA=0).
+int device_numa_node(int logical)
+{
+    static std::mutex mu;
+    static int cached[kMaxDevices];
+    static bool known[kMaxDevices] = {};
+    if (!numa::enabled() || logical < 0 || logical >= kMaxDevices || physical_count() <= 0) return -1;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!known[logical]) {
+        char bdf[64] = {};
+        int node = -1;
+        if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf - 1, physical_of(logical)) == hipSuccess) {
+            for (char *c = bdf; *c; ++c) *c = (char)std::tolower((unsigned char)*c); // sysfs spells it lower-case
+            node = numa::node_of_pci("/sys", bdf);
+        } else {
+            (void)hipGetLastError();
+        }
+        cached[logical] = node;
+        known[logical] = true;
+    }
+    return cached[logical];
+}
+
+void run_near_device(int logical)
+{
+    const int node = device_numa_node(logical);
+    if (node >= 0) (void)numa::run_on_node("/sys", node);
+}
+
+DeviceScope::DeviceScope(int device, bool always_save)
+{
+    if ((device >= 0 || always_save) && hipGetDevice(&prev_) != hipSuccess) {
+        (void)hipGetLastError();
+        prev_ = -1;
+    }
+    rc = device >= 0 || !always_save ? select_device(device) : MODGPU_OK;
+}
+
+DeviceScope::~DeviceScope()
+{
+    if (prev_ >= 0) (void)hipSetDevice(prev_); // the caller's thread keeps the device it came with
+}
+
 // ---- launch planning -----------------------------------------------------------------
 
 namespace {
@@ -122,12 +183,22 @@ struct Plan {
     CycleArgs args;
     int variant;
     uint32_t grid;
+    int queue_line = -1; // ring line held by this launch (given back if the launch fails), with its device
+    int queue_dev = -1;
 };
 
-// test hooks (include/modgpu_testing.h): forced shape / grid cap, and the calling thread's last launch
+// the calling thread's last launch (modgpu_last_launch: reporting only)
+thread_local modgpu_launch_info_t t_last_launch{};
+// forced shape / grid cap: exist only in the testing flavour of the library (libmodgpu_testing.so)
+#ifdef MODGPU_TESTING_HOOKS
 std::atomic<int> g_force_variant{-1};
 std::atomic<uint32_t> g_grid_cap{0};
-thread_local modgpu_launch_info_t t_last_launch{};
+int forced_variant() { return g_force_variant.load(std::memory_order_relaxed); }
+uint32_t forced_grid_cap() { return g_grid_cap.load(std::memory_order_relaxed); }
+#else
+constexpr int forced_variant() { return -1; }
+constexpr uint32_t forced_grid_cap() { return 0; }
+#endif
 
 // Streaming shape: one persistent 1024-thread workgroup per CU (4 waves/SIMD), so the grid is the
 // device's CU count (256 on MI355X), looked up once per device.
@@ -146,42 +217,127 @@ uint32_t large_grid()
     return cus[dev];
 }
 // Work-queue shape: every launch needs a {ticket, done} pair that is zero when it starts; the kernel's last
-// workgroup zeroes it again, so a per-device ring of pairs (one 64-byte line each), handed out round-robin,
-// is allocated and cleared once.  A pair is reused after kQueueRing later launches on that device.
-constexpr uint32_t kQueueRing = 256;
+// workgroup zeroes it again and then signs off in a host-visible word, so a per-device ring of pairs (one 64-byte
+// line each) is allocated and cleared once.  Two launches must never share a pair while either runs (their
+// tickets would interleave: chunks skipped in one, done twice in neither -- wrong bytes, no error), so
+//   * an eager launch takes a ring line only if the line's previous user has signed off (done[line] ==
+//     issued[line], a plain read of host-coherent memory: no HIP call, nothing extra on the stream); if every
+//     line is busy the launch takes the static streaming shape, which needs no pair;
+//   * a launch that is being captured into a hipGraph is baked into the graph together with its pair, and may
+//     be replayed at any later time, so it never draws from the ring: it gets a line of its own from a
+//     separate grow-only pool that is never handed out again (pool empty: static shape).
+constexpr uint32_t kQueueRing = 256;  // eager lines
+constexpr uint32_t kGraphPool = 1024; // lines owned by captured launches, for the life of the process
 struct QueueRing {
     std::mutex mu;
-    std::atomic<uint32_t *> base{nullptr}; // kQueueRing lines of 16 words
-    std::atomic<uint32_t> next{0};
+    std::atomic<uint32_t *> base{nullptr}; // device: (kQueueRing + kGraphPool) lines of 16 words, all zero between launches
+    volatile uint32_t *done = nullptr;     // host-coherent pinned memory: one word per ring line, written by the kernel
+    uint32_t *done_dev = nullptr;          // the same words as the device addresses them
+    uint32_t issued[kQueueRing] = {};      // sequence number given to the line's latest user   (under mu)
+    uint32_t next = 0;                     // where the search for a free line starts           (under mu)
+    uint32_t graph_used = 0;               // pool lines given away                             (under mu)
 };
 QueueRing g_queue_ring[kMaxDevices];
+std::atomic<uint64_t> g_queue_eager{0}, g_queue_busy{0}, g_queue_graph{0}, g_queue_graph_full{0};
+#ifdef MODGPU_TESTING_HOOKS
+std::atomic<uint32_t> g_ring_lines{kQueueRing}; // modgpu_debug_set_queue_ring: a ring of 1 makes every overlap a collision
+uint32_t ring_lines() { return g_ring_lines.load(std::memory_order_relaxed); }
+#else
+constexpr uint32_t ring_lines() { return kQueueRing; }
+#endif
 
-// nullptr: no pair available right now (first use while the stream is being captured into a graph --
-// allocating there would break the capture -- or the allocation failed): the caller takes the static shape.
-uint32_t *queue_pair(hipStream_t stream)
+struct QueuePair {
+    uint32_t *pair = nullptr; // nullptr: none available -> static shape
+    uint32_t *done = nullptr;
+    uint32_t seq = 0;
+    int line = -1; // ring line to give back if the launch does not happen; -1: pool line / none
+    int dev = -1;
+};
+
+// One-time set-up of a device's ring.  Not possible while `stream` is being captured (allocating there
+// would break the capture); other threads' captures are kept out of it by relaxed capture mode.
+bool queue_ring_create(QueueRing &r, hipStream_t stream)
 {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-    QueueRing &r = g_queue_ring[dev];
-    uint32_t *base = r.base.load(std::memory_order_acquire);
-    if (!base) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        std::lock_guard<std::mutex> lock(r.mu);
-        base = r.base.load(std::memory_order_acquire);
-        if (!base) {
-            uint32_t *p = nullptr;
-            if (hipMalloc(reinterpret_cast<void **>(&p), kQueueRing * 64) != hipSuccess || hipMemset(p, 0, kQueueRing * 64) != hipSuccess) {
-                (void)hipGetLastError();
-                return nullptr;
-            }
-            r.base.store(base = p, std::memory_order_release);
-        }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return false;
     }
-    return base + (size_t)(r.next.fetch_add(1, std::memory_order_relaxed) % kQueueRing) * 16;
+    std::lock_guard<std::mutex> lock(r.mu);
+    if (r.base.load(std::memory_order_acquire)) return true;
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    uint32_t *lines = nullptr, *done = nullptr, *done_dev = nullptr;
+    hipStream_t st = nullptr;
+    const size_t bytes = (size_t)(kQueueRing + kGraphPool) * 64;
+    bool ok = hipMalloc(reinterpret_cast<void **>(&lines), bytes) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void **>(&done), kQueueRing * sizeof(uint32_t),
+                            hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+              hipHostGetDevicePointer(reinterpret_cast<void **>(&done_dev), done, 0) == hipSuccess &&
+              // the zeroes are in place before the ring is published: a kernel on ANY stream (non-blocking ones
+              // included) may be the first user
+              hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+              hipMemsetAsync(lines, 0, bytes, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    if (st) (void)hipStreamDestroy(st);
+    if (ok) {
+        std::memset(done, 0, kQueueRing * sizeof(uint32_t));
+        r.done = done;
+        r.done_dev = done_dev;
+        r.base.store(lines, std::memory_order_release);
+    } else {
+        (void)hipGetLastError();
+        if (lines) (void)hipFree(lines);
+        if (done) (void)hipHostFree(done);
+    }
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    return ok;
+}
+
+QueuePair queue_pair(hipStream_t stream)
+{
+    QueuePair q;
+    if (hipGetDevice(&q.dev) != hipSuccess || q.dev < 0 || q.dev >= kMaxDevices) return q;
+    QueueRing &r = g_queue_ring[q.dev];
+    if (!r.base.load(std::memory_order_acquire) && !queue_ring_create(r, stream)) return q;
+    uint32_t *base = r.base.load(std::memory_order_acquire);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        return q;
+    }
+    std::lock_guard<std::mutex> lock(r.mu);
+    if (cap != hipStreamCaptureStatusNone) { // the graph keeps its line for good
+        if (r.graph_used >= kGraphPool) {
+            g_queue_graph_full.fetch_add(1, std::memory_order_relaxed);
+            return q;
+        }
+        q.pair = base + (size_t)(kQueueRing + r.graph_used++) * 16;
+        g_queue_graph.fetch_add(1, std::memory_order_relaxed);
+        return q;
+    }
+    const uint32_t lines = std::max(1u, std::min(ring_lines(), kQueueRing));
+    for (uint32_t k = 0; k < lines; ++k) {
+        const uint32_t line = (r.next + k) % lines;
+        if (r.done[line] != r.issued[line]) continue; // its latest user has not signed off yet
+        r.next = line + 1;
+        q.pair = base + (size_t)line * 16;
+        q.done = r.done_dev + line;
+        q.seq = ++r.issued[line];
+        q.line = (int)line;
+        g_queue_eager.fetch_add(1, std::memory_order_relaxed);
+        return q;
+    }
+    g_queue_busy.fetch_add(1, std::memory_order_relaxed);
+    return q;
+}
+
+// The launch that took this ring line did not happen: nobody will sign off for it.
+void queue_pair_unused(const QueuePair &q)
+{
+    if (q.line < 0 || q.dev < 0) return;
+    QueueRing &r = g_queue_ring[q.dev];
+    std::lock_guard<std::mutex> lock(r.mu);
+    --r.issued[q.line];
 }
 
 constexpr uint32_t kSmallGridMax = 16384u;   // 4 KiB chunks: grid * 1 tile <= 65536
@@ -220,11 +376,17 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
 
     uint64_t body_bytes = words * 16;
     p.variant = body_bytes >= kLargeMin && !over_pcie ? CYCLE_QUEUE : CYCLE_SMALL;
-    const int forced = g_force_variant.load(std::memory_order_relaxed);
+    const int forced = forced_variant();
     if (forced >= 0 && forced < kCycleVariants) p.variant = forced;
     uint64_t chunk = modgpu_variant_chunk_bytes(p.variant);
-    if (p.variant == CYCLE_QUEUE) { // needs a clean ticket pair and chunk indices that fit its 3-byte jump tables
-        a.queue = (body_bytes + chunk) / chunk + 4ull * 2048 < (1ull << 24) ? queue_pair(stream) : nullptr;
+    if (p.variant == CYCLE_QUEUE) { // needs a clean ticket pair of its own and chunk indices that fit its 3-byte jump tables
+        QueuePair q;
+        if ((body_bytes + chunk) / chunk + 4ull * 2048 < (1ull << 24)) q = queue_pair(stream);
+        a.queue = q.pair;
+        a.queue_done = q.done;
+        a.queue_seq = q.seq;
+        p.queue_line = q.line;
+        p.queue_dev = q.dev;
         if (!a.queue) {
             p.variant = CYCLE_LARGE;
             chunk = modgpu_variant_chunk_bytes(p.variant);
@@ -241,7 +403,7 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
     // +2.4 % at 402 MiB over one per CU; 160 and below fall off (profiles/r02_tune_cycle_queue_grid.txt).
     if (p.variant == CYCLE_QUEUE) cap = std::max<uint64_t>(1, cap * 25 / 32);
     if (over_pcie) cap = std::min<uint64_t>(cap, kPcieGridMax);
-    const uint32_t grid_cap = g_grid_cap.load(std::memory_order_relaxed);
+    const uint32_t grid_cap = forced_grid_cap();
     if (grid_cap >= 1 && grid_cap < cap) cap = grid_cap;
     p.grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(chunks, cap));
     // one grid trip advances every lane-word by grid chunks
@@ -259,7 +421,15 @@ int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_of
     if (key_res == 0) return MODGPU_OK; // keystream is all zero (state sticks at m): identity
     Plan p = plan_cycle(dev_buf, n, key_res, stream_off, over_pcie, stream);
     hipError_t e = modgpu_launch_cycle(p.args, p.variant, p.grid, stream);
-    if (e != hipSuccess) return fail_hip(e, "cycle kernel launch");
+    if (e != hipSuccess) {
+        if (p.queue_line >= 0) {
+            QueuePair q;
+            q.line = p.queue_line;
+            q.dev = p.queue_dev;
+            queue_pair_unused(q);
+        }
+        return fail_hip(e, "cycle kernel launch");
+    }
     g_stats.gpu_launches.fetch_add(1, std::memory_order_relaxed);
     t_last_launch = {modgpu_variant_kernel_name(p.variant), p.variant, p.grid, modgpu_variant_block(p.variant),
                      modgpu_variant_chunk_bytes(p.variant), n};
@@ -268,11 +438,17 @@ int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_of
 
 // ---- page-locked host memory ----------------------------------------------------------------
 namespace {
+enum class HostKind {
+    HipHost,    // hipHostMalloc
+    Plain,      // posix_memalign: no GPU, or the pages could not be locked
+    Registered, // the caller's own memory, pinned in place by modgpu_host_register (never freed here)
+    Placed,     // our own mmap with a NUMA policy per part, pinned in place by hipHostRegister (or not pinned: see `pinned`)
+};
 struct HostRange {
     uintptr_t base;
     uint64_t size;
-    bool pinned;     // page-locked and device-visible (else posix_memalign: no GPU when it was allocated)
-    bool registered; // the caller's own memory, pinned in place by modgpu_host_register (never freed here)
+    bool pinned; // page-locked and device-visible
+    HostKind kind;
 };
 std::mutex g_host_mu;
 std::vector<HostRange> g_host_ranges; // few, long-lived allocations: linear scan
@@ -301,11 +477,12 @@ int cycle_host_impl(uint8_t *host, uint64_t n, int32_t key, uint64_t stream_off,
     return stream_impl(e, e, n, key, stream_off, device, touched);
 }
 
-int scalar_impl(uint8_t *host, uint64_t n, int32_t key, uint64_t stream_off)
+int scalar_impl(uint8_t *host, uint64_t n, int32_t key, uint64_t stream_off, int isa = MODGPU_ISA_AUTO)
 {
     if (n && !host) return fail(MODGPU_ERR_INVALID, "null host buffer");
     if (gpu_required()) return fail(MODGPU_ERR_FORBIDDEN, "host loop forbidden by MODGPU_REQUIRE_GPU");
-    modgpu_scalar_cycle(host, n, key, stream_off);
+    if (isa != MODGPU_ISA_AUTO && !modgpu_scalar_isa_usable(isa)) return fail(MODGPU_ERR_INVALID, "this CPU does not run that host-loop body");
+    modgpu_scalar_cycle(host, n, key, stream_off, isa);
     g_stats.scalar_calls.fetch_add(1, std::memory_order_relaxed);
     g_stats.scalar_bytes.fetch_add(n, std::memory_order_relaxed);
     return MODGPU_OK;
@@ -341,8 +518,8 @@ int modgpu_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_
                         void *hip_stream)
 {
     return guarded([&]() -> int {
-        int rc = select_device(device);
-        if (rc) return rc;
+        DeviceScope scope(device);
+        if (scope.rc) return scope.rc;
         return cycle_device_impl(dev_buf, n, key, stream_off, static_cast<hipStream_t>(hip_stream));
     });
 }
@@ -360,6 +537,14 @@ int modgpu_cycle_scalar_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_
 int modgpu_cycle_auto_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, int device)
 {
     return guarded([&]() -> int {
+        // `if (n < threshold || !gpu_ok) cpu_loop(); else ...`.  The reference's call sites pass headers
+        // (CArk.cpp:338-339, 1135-1136, Modulate.cpp:485-486; <= 512 KiB by CArk.cpp:911-912): below the measured
+        // crossover the host loop is the faster engine.  MODGPU_REQUIRE_GPU=1 keeps every size on the kernel.
+        if (n < min_gpu_bytes() && !gpu_required()) {
+            int rc = scalar_impl(host_buf, n, key, stream_off);
+            if (rc == MODGPU_OK && n) g_stats.auto_small.fetch_add(1, std::memory_order_relaxed);
+            return rc;
+        }
         bool touched = false;
         int rc = cycle_host_impl(host_buf, n, key, stream_off, device, &touched);
         if (rc == MODGPU_OK || rc == MODGPU_ERR_INVALID) return rc;
@@ -410,7 +595,8 @@ int modgpu_cycle_parts_host(uint8_t *const *parts, const uint64_t *sizes, int n_
         n_devices = std::min(n_devices, std::max(n_parts, 1));
         std::vector<int> rcs((size_t)n_devices, MODGPU_OK);
         std::vector<std::string> errs((size_t)n_devices);
-        auto body = [&](int d) {
+        auto body = [&](int d, bool own_thread) {
+            if (own_thread) run_near_device(d); // this worker's copies run on the socket its GPU hangs off
             for (int i = d; i < n_parts; i += n_devices) { // part i -> GPU i mod N
                 int rc = cycle_host_impl(parts[i], sizes[i], key, 0, d, nullptr);
                 if (rc) {
@@ -423,11 +609,11 @@ int modgpu_cycle_parts_host(uint8_t *const *parts, const uint64_t *sizes, int n_
         std::vector<std::thread> workers;
         int started = 1; // device 0's parts are done on the calling thread
         try {
-            for (int d = 1; d < n_devices; ++d, ++started) workers.emplace_back(body, d);
+            for (int d = 1; d < n_devices; ++d, ++started) workers.emplace_back(body, d, true);
         } catch (...) { // thread limit: the remaining devices' parts are done here, one device after another
         }
-        body(0);
-        for (int d = started; d < n_devices; ++d) body(d);
+        body(0, false);
+        for (int d = started; d < n_devices; ++d) body(d, false);
         for (auto &w : workers) w.join();
         for (int d = 0; d < n_devices; ++d)
             if (rcs[d]) {
@@ -442,6 +628,7 @@ int modgpu_cycle_parts_device(void *const *dev_parts, const uint64_t *sizes, con
 {
     return guarded([&]() -> int {
         if (n_parts < 0 || (n_parts > 0 && (!dev_parts || !sizes || !devices))) return fail(MODGPU_ERR_INVALID, "bad part list");
+        DeviceScope keep(-1, /*always_save=*/true); // this thread visits every part's GPU and leaves as it came
         int rc = MODGPU_OK;
         int launched = 0;
         for (; launched < n_parts && rc == MODGPU_OK; ++launched) { // every part its own Cycle from stream offset 0
@@ -479,7 +666,7 @@ int modgpu_host_alloc(void **host_ptr, uint64_t n)
         if (!p && ::posix_memalign(&p, 64, bytes) != 0) return fail(MODGPU_ERR_INVALID, "out of host memory");
         {
             std::lock_guard<std::mutex> lock(g_host_mu);
-            g_host_ranges.push_back({reinterpret_cast<uintptr_t>(p), bytes, pinned, false});
+            g_host_ranges.push_back({reinterpret_cast<uintptr_t>(p), bytes, pinned, pinned ? HostKind::HipHost : HostKind::Plain});
         }
         *host_ptr = p;
         return MODGPU_OK;
@@ -490,22 +677,91 @@ int modgpu_host_free(void *host_ptr)
 {
     return guarded([&]() -> int {
         if (!host_ptr) return MODGPU_OK;
-        bool pinned = false, found = false;
+        HostRange r{};
+        bool found = false;
         {
             std::lock_guard<std::mutex> lock(g_host_mu);
             for (size_t i = 0; i < g_host_ranges.size(); ++i)
-                if (g_host_ranges[i].base == reinterpret_cast<uintptr_t>(host_ptr) && !g_host_ranges[i].registered) {
-                    pinned = g_host_ranges[i].pinned;
+                if (g_host_ranges[i].base == reinterpret_cast<uintptr_t>(host_ptr) && g_host_ranges[i].kind != HostKind::Registered) {
+                    r = g_host_ranges[i];
                     g_host_ranges.erase(g_host_ranges.begin() + (long)i);
                     found = true;
                     break;
                 }
         }
         if (!found) return fail(MODGPU_ERR_INVALID, "not a modgpu_host_alloc pointer");
-        if (pinned) HIP_TRY(hipHostFree(host_ptr));
-        else std::free(host_ptr);
+        if (r.kind == HostKind::Placed) {
+            hipError_t e = r.pinned ? hipHostUnregister(host_ptr) : hipSuccess;
+            numa::release(host_ptr, r.size);
+            if (e != hipSuccess) return fail_hip(e, "hipHostUnregister");
+        } else if (r.kind == HostKind::HipHost) {
+            HIP_TRY(hipHostFree(host_ptr));
+        } else {
+            std::free(host_ptr);
+        }
         return MODGPU_OK;
     });
+}
+
+int modgpu_host_alloc_parts(void **host_ptr, const uint64_t *sizes, int n_parts, int n_devices)
+{
+    return guarded([&]() -> int {
+        if (!host_ptr || n_parts < 0 || (n_parts > 0 && !sizes)) return fail(MODGPU_ERR_INVALID, "bad part list");
+        *host_ptr = nullptr;
+        uint64_t total = 0;
+        for (int i = 0; i < n_parts; ++i) total += sizes[i];
+        const int avail = logical_count();
+        if (n_devices <= 0 || n_devices > avail) n_devices = avail;
+        // without a GPU, or with placement switched off, this is modgpu_host_alloc
+        if (avail <= 0 || !numa::enabled()) return modgpu_host_alloc(host_ptr, total);
+        const uint64_t bytes = total ? total : 1;
+        void *p = numa::reserve(bytes);
+        if (!p) return fail(MODGPU_ERR_INVALID, "out of host memory");
+        // part i -> GPU i mod n_devices (the rule of modgpu_cycle_parts_host): its whole pages go to that GPU's node
+        // (a page shared by two parts stays with the default policy); pages are faulted in by the registration below
+        uint64_t off = 0;
+        for (int i = 0; i < n_parts; ++i) {
+            (void)numa::prefer_node(static_cast<uint8_t *>(p) + off, sizes[i], device_numa_node(i % n_devices));
+            off += sizes[i];
+        }
+        bool pinned = hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess;
+        if (!pinned) (void)hipGetLastError(); // e.g. the locked-memory limit: ordinary memory, staged route
+        {
+            std::lock_guard<std::mutex> lock(g_host_mu);
+            g_host_ranges.push_back({reinterpret_cast<uintptr_t>(p), bytes, pinned, HostKind::Placed});
+        }
+        *host_ptr = p;
+        return MODGPU_OK;
+    });
+}
+
+int modgpu_host_alloc_near(void **host_ptr, uint64_t n, int device)
+{
+    return guarded([&]() -> int {
+        if (!host_ptr) return fail(MODGPU_ERR_INVALID, "null out pointer");
+        const int avail = logical_count();
+        if (avail > 0 && (device < 0 || device >= avail)) return fail(MODGPU_ERR_INVALID, "device index out of range");
+        if (avail <= 0 || device_numa_node(device) < 0) return modgpu_host_alloc(host_ptr, n); // nothing to place by
+        *host_ptr = nullptr;
+        const uint64_t bytes = n ? n : 1;
+        void *p = numa::reserve(bytes);
+        if (!p) return fail(MODGPU_ERR_INVALID, "out of host memory");
+        (void)numa::prefer_node(p, bytes, device_numa_node(device));
+        bool pinned = hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess;
+        if (!pinned) (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lock(g_host_mu);
+            g_host_ranges.push_back({reinterpret_cast<uintptr_t>(p), bytes, pinned, HostKind::Placed});
+        }
+        *host_ptr = p;
+        return MODGPU_OK;
+    });
+}
+
+int modgpu_device_numa_node(int device)
+{
+    if (device < 0 || device >= logical_count()) return -1;
+    return device_numa_node(device);
 }
 
 int modgpu_host_register(void *host_ptr, uint64_t n)
@@ -516,7 +772,7 @@ int modgpu_host_register(void *host_ptr, uint64_t n)
         hipError_t e = hipHostRegister(host_ptr, n, hipHostRegisterPortable | hipHostRegisterMapped);
         if (e != hipSuccess) return fail_hip(e, "hipHostRegister");
         std::lock_guard<std::mutex> lock(g_host_mu);
-        g_host_ranges.push_back({reinterpret_cast<uintptr_t>(host_ptr), n, true, true});
+        g_host_ranges.push_back({reinterpret_cast<uintptr_t>(host_ptr), n, true, HostKind::Registered});
         return MODGPU_OK;
     });
 }
@@ -529,7 +785,7 @@ int modgpu_host_unregister(void *host_ptr)
         {
             std::lock_guard<std::mutex> lock(g_host_mu);
             for (size_t i = 0; i < g_host_ranges.size(); ++i)
-                if (g_host_ranges[i].base == reinterpret_cast<uintptr_t>(host_ptr) && g_host_ranges[i].registered) {
+                if (g_host_ranges[i].base == reinterpret_cast<uintptr_t>(host_ptr) && g_host_ranges[i].kind == HostKind::Registered) {
                     g_host_ranges.erase(g_host_ranges.begin() + (long)i);
                     found = true;
                     break;
@@ -555,17 +811,22 @@ int modgpu_path_stats(modgpu_path_stats_t *out, int reset)
     out->staged_bytes = take(g_stats.staged_bytes);
     out->direct_bytes = take(g_stats.direct_bytes);
     out->auto_fallbacks = take(g_stats.auto_fallbacks);
+    out->auto_small = take(g_stats.auto_small);
     return MODGPU_OK;
 }
 
 int modgpu_gpu_required(void) { return gpu_required() ? 1 : 0; }
 
+uint64_t modgpu_min_gpu_bytes(void) { return min_gpu_bytes(); }
+
+const char *modgpu_host_loop_isa(void) { return modgpu_scalar_isa_name(modgpu_scalar_isa()); }
+
 int modgpu_alloc(void **dev_ptr, uint64_t n, int device)
 {
     return guarded([&]() -> int {
         if (!dev_ptr) return fail(MODGPU_ERR_INVALID, "null out pointer");
-        int rc = select_device(device);
-        if (rc) return rc;
+        DeviceScope scope(device);
+        if (scope.rc) return scope.rc;
         HIP_TRY(hipMalloc(dev_ptr, n ? n : 1));
         return MODGPU_OK;
     });
@@ -574,8 +835,8 @@ int modgpu_alloc(void **dev_ptr, uint64_t n, int device)
 int modgpu_free(void *dev_ptr, int device)
 {
     return guarded([&]() -> int {
-        int rc = select_device(device);
-        if (rc) return rc;
+        DeviceScope scope(device);
+        if (scope.rc) return scope.rc;
         HIP_TRY(hipFree(dev_ptr));
         return MODGPU_OK;
     });
@@ -584,8 +845,8 @@ int modgpu_free(void *dev_ptr, int device)
 int modgpu_h2d(void *dev_dst, const void *host_src, uint64_t n, int device)
 {
     return guarded([&]() -> int {
-        int rc = select_device(device);
-        if (rc) return rc;
+        DeviceScope scope(device);
+        if (scope.rc) return scope.rc;
         if (n) HIP_TRY(hipMemcpy(dev_dst, host_src, n, hipMemcpyHostToDevice));
         return MODGPU_OK;
     });
@@ -594,8 +855,8 @@ int modgpu_h2d(void *dev_dst, const void *host_src, uint64_t n, int device)
 int modgpu_d2h(void *host_dst, const void *dev_src, uint64_t n, int device)
 {
     return guarded([&]() -> int {
-        int rc = select_device(device);
-        if (rc) return rc;
+        DeviceScope scope(device);
+        if (scope.rc) return scope.rc;
         if (n) HIP_TRY(hipMemcpy(host_dst, dev_src, n, hipMemcpyDeviceToHost));
         return MODGPU_OK;
     });
@@ -604,8 +865,8 @@ int modgpu_d2h(void *host_dst, const void *dev_src, uint64_t n, int device)
 int modgpu_sync(int device, void *hip_stream)
 {
     return guarded([&]() -> int {
-        int rc = select_device(device);
-        if (rc) return rc;
+        DeviceScope scope(device);
+        if (scope.rc) return scope.rc;
         HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
         return MODGPU_OK;
     });
@@ -641,8 +902,9 @@ int modgpu_time_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t st
 {
     return guarded([&]() -> int {
         if (iters <= 0 || !ms_per_launch) return fail(MODGPU_ERR_INVALID, "bad timing arguments");
-        int rc = select_device(device);
-        if (rc) return rc;
+        DeviceScope scope(device);
+        if (scope.rc) return scope.rc;
+        int rc = MODGPU_OK;
         hipStream_t st = static_cast<hipStream_t>(hip_stream);
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0));
@@ -670,6 +932,45 @@ int modgpu_last_launch(modgpu_launch_info_t *out)
     return MODGPU_OK;
 }
 
+int modgpu_cycle_scalar_host_isa(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, const char *isa)
+{
+    return guarded([&]() -> int {
+        for (int i = 0; isa && i < MODGPU_ISA_COUNT; ++i)
+            if (std::strcmp(isa, modgpu_scalar_isa_name(i)) == 0) return scalar_impl(host_buf, n, key, stream_off, i);
+        return fail(MODGPU_ERR_INVALID, "unknown host-loop body");
+    });
+}
+
+int modgpu_numa_probe(const char *sysfs_root, const char *bdf, int *node, int *cpus, int max_cpus)
+{
+    if (!sysfs_root || !bdf || !node) return -1;
+    *node = numa::node_of_pci(sysfs_root, bdf);
+    const std::vector<int> list = numa::cpus_of_node(sysfs_root, *node);
+    int n = 0;
+    for (; n < (int)list.size() && cpus && n < max_cpus; ++n) cpus[n] = list[(size_t)n];
+    return n;
+}
+
+void modgpu_queue_stats(uint64_t out[4])
+{
+    out[0] = g_queue_eager.load();
+    out[1] = g_queue_busy.load();
+    out[2] = g_queue_graph.load();
+    out[3] = g_queue_graph_full.load();
+}
+
+const char *modgpu_kernel_source_hash(void) { return MODGPU_KERNEL_SOURCE_HASH; }
+
+int modgpu_testing_hooks(void)
+{
+#ifdef MODGPU_TESTING_HOOKS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+#ifdef MODGPU_TESTING_HOOKS
 void modgpu_debug_set_launch(int variant, uint32_t grid_cap)
 {
     g_force_variant.store(variant, std::memory_order_relaxed);
@@ -679,6 +980,10 @@ void modgpu_debug_set_launch(int variant, uint32_t grid_cap)
 void modgpu_debug_set_pinned_mode(int mode) { g_pinned_mode.store(mode, std::memory_order_relaxed); }
 void modgpu_debug_set_staged_mode(int mode) { g_staged_mode.store(mode, std::memory_order_relaxed); }
 
-const char *modgpu_kernel_source_hash(void) { return MODGPU_KERNEL_SOURCE_HASH; }
+void modgpu_debug_set_queue_ring(uint32_t lines)
+{
+    g_ring_lines.store(lines == 0 ? kQueueRing : std::min(lines, kQueueRing), std::memory_order_relaxed);
+}
+#endif
 
 } // extern "C"

@@ -51,6 +51,24 @@ int physical_of(int logical);
 int select_device(int device);
 // Same, and returns the logical index in *out (the current HIP ordinal when device < 0).
 int resolve_device(int device, int *out);
+// select_device for the length of a scope: an entry point called with device >= 0 works on that GPU and puts the
+// calling thread's current HIP device back when it returns (a torch process must not find its device switched).
+class DeviceScope {
+public:
+    explicit DeviceScope(int device, bool always_save = false);
+    ~DeviceScope();
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+    int rc = MODGPU_OK; // select_device's status
+
+private:
+    int prev_ = -1;
+};
+
+// NUMA node of the GPU behind a logical device (-1 unknown / MODGPU_NUMA=0); and: restrict the calling (worker)
+// thread to that node's CPUs.  Both best effort.
+int device_numa_node(int logical);
+void run_near_device(int logical);
 
 // ---- the launch (device already current) ----------------------------------------------------
 // over_pcie: dev_buf is page-locked HOST memory the kernel reaches across PCIe -- planned with the shape
@@ -61,7 +79,7 @@ int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_of
 // ---- which engine ran -------------------------------------------------------------------------
 struct Stats {
     std::atomic<uint64_t> gpu_calls{0}, gpu_bytes{0}, gpu_launches{0}, scalar_calls{0}, scalar_bytes{0},
-        staged_bytes{0}, direct_bytes{0}, auto_fallbacks{0};
+        staged_bytes{0}, direct_bytes{0}, auto_fallbacks{0}, auto_small{0};
 };
 extern Stats g_stats;
 bool gpu_required(); // MODGPU_REQUIRE_GPU=1 at load
@@ -83,7 +101,9 @@ struct Endpoint {
 // caller with a second engine knows whether it can still start over.
 int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t key, uint64_t stream_off, int device,
                 bool *touched);
+#ifdef MODGPU_TESTING_HOOKS
 extern std::atomic<int> g_pinned_mode; // modgpu_debug_set_pinned_mode
 extern std::atomic<int> g_staged_mode; // modgpu_debug_set_staged_mode
+#endif
 
 } // namespace modgpu

@@ -1,0 +1,38 @@
+// numa_place.h -- where host memory and host threads sit relative to a GPU (numa_place.cpp).  No HIP.
+//
+// The part path is the only multi-GPU path that shares a resource: host DRAM and the PCIe root
+// complexes.  On a two-socket 8-GPU node a part's pages and the threads that copy them
+// should live on the socket its GPU hangs off; everything here is best effort -- when the topology
+// cannot be read, or MODGPU_NUMA=0, nothing is bound and everything still works.
+#pragma once
+#include <cstddef>
+#include <string>
+#include <vector>
+
+namespace modgpu {
+namespace numa {
+
+bool enabled(); // MODGPU_NUMA is not "0" (read once)
+
+// "0-3,8,10-11" -> {0,1,2,3,8,10,11}.  Malformed pieces are skipped.
+std::vector<int> parse_cpulist(const std::string &text);
+
+// NUMA node of PCI function `bdf` ("0000:c1:00.0"): <sysfs>/bus/pci/devices/<bdf>/numa_node.  -1 = unknown
+// (file missing, or the kernel's own -1 on single-node machines).
+int node_of_pci(const std::string &sysfs, const std::string &bdf);
+
+// CPUs of a node: <sysfs>/devices/system/node/node<N>/cpulist.  Empty = unknown.
+std::vector<int> cpus_of_node(const std::string &sysfs, int node);
+
+// Page-aligned anonymous memory whose pages will be faulted in on `node` (mbind, MPOL_PREFERRED: falls back to
+// other nodes rather than failing).  node < 0: no policy.  nullptr on failure.  Release with release().
+void *reserve(size_t bytes);
+void release(void *p, size_t bytes);
+// Binds the whole pages inside [p, p + bytes) to `node`; call before the pages are first touched.  0 = done.
+int prefer_node(void *p, size_t bytes, int node);
+
+// Restricts the calling thread to the CPUs of `node` (sched_setaffinity).  0 = done, -1 = left as it was.
+int run_on_node(const std::string &sysfs, int node);
+
+} // namespace numa
+} // namespace modgpu

@@ -1,17 +1,28 @@
-// scalar_path.cpp -- the library's own HOST implementation of the cipher, for machines without a
-// usable GPU (the reference's Cycle "cannot fail", Modulate/CEncryptionCycler.cpp:4-14).
+// scalar_path.cpp -- the library's own HOST implementation of the cipher: for machines without a
+// usable GPU (the reference's Cycle "cannot fail", Modulate/CEncryptionCycler.cpp:4-14) and for the
+// header-sized buffers the reference's three call sites pass (CArk.cpp:338-339, 1135-1136,
+// Modulate.cpp:485-486), where a kernel launch + wait costs more than the arithmetic.
 //
 // Product code: built from lcg.h's closed form  s_i = a^(i+1) * key mod m  like the kernel, not
 // from the reference's Schrage step, and it shares nothing with the checker under oracle/.  No HIP
-// in this file, so the sanitizer build (make sanitize) compiles it as is.
+// in this file, so the sanitizer builds compile it as is.
 //
-// Layout mirrors one GPU lane-word: sixteen independent byte states S_j = S * a^j, each advanced by
-// a^16 per 16-byte word, so there is no serial dependency between neighbouring bytes and the
-// compiler can keep the sixteen 32x32->64 multiplies in vector registers.  Buffers of 4 MiB and up
-// are cut into contiguous spans, one per host thread (every span jumps to its own position).
+// Layout mirrors the GPU's lane-words: W independent byte states S_j = S * a^j, each advanced by a^W
+// per W-byte block, so there is no serial dependency between neighbouring bytes.  Three bodies, picked
+// once per process from what the CPU offers (MODGPU_HOST_ISA=generic|avx2|avx512 overrides):
+//   generic  W = 16, plain C++ (the compiler keeps the sixteen 32x32->64 multiplies in registers)
+//   avx2     W = 32: eight ymm registers of four states (vpmuludq), Mersenne fold, packed to 32 bytes
+//   avx512   W = 64: the same with zmm registers (AVX-512 F + BW)
+// Buffers of a few MiB and up are cut into contiguous spans, one per host thread (every span jumps
+// to its own position).
 #include "scalar_path.h"
 
+#include <immintrin.h>
+#include <sched.h>
+
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -27,7 +38,7 @@ inline uint32_t mulmod_fold(uint32_t x, uint32_t y)
     return r >= lcg::M ? r - lcg::M : r;
 }
 
-void span_cycle(uint8_t *buf, uint64_t n, uint32_t key_res, uint64_t pos)
+void span_generic(uint8_t *buf, uint64_t n, uint32_t key_res, uint64_t pos)
 {
     constexpr int W = lcg::WORD;
     const uint32_t step = lcg::mulmod(lcg::kBytePow.v[W - 1], lcg::A); // a^16
@@ -46,29 +57,193 @@ void span_cycle(uint8_t *buf, uint64_t n, uint32_t key_res, uint64_t pos)
     for (int j = 0; i < n; ++i, ++j) buf[i] ^= (uint8_t)~s[j];
 }
 
+// Vector bodies.  R registers of L 64-bit lanes hold R*L = W states in the lanes' low halves (vpmuludq
+// multiplies exactly those).  Register pairs are merged into 32-bit lanes, masked to the low byte and
+// narrowed twice with the in-lane pack instructions; the packs interleave, so state (register 2k+o,
+// lane l) ends up at byte  16*(l/2) + 4*k + 2*(l&1) + o  of the block -- the states are simply
+// initialised in that order.
+inline int packed_byte(int reg, int lane) { return 16 * (lane / 2) + 4 * (reg / 2) + 2 * (lane & 1) + (reg & 1); }
+
+__attribute__((target("avx2"))) void span_avx2(uint8_t *buf, uint64_t n, uint32_t key_res, uint64_t pos)
+{
+    constexpr int W = 32, R = 8, L = 4;
+    uint32_t s[W];
+    s[0] = lcg::state_residue(key_res, pos);
+    for (int j = 1; j < W; ++j) s[j] = mulmod_fold(s[j - 1], lcg::A);
+    const uint32_t step = lcg::powmod(lcg::A, W);
+    alignas(32) uint64_t init[R][L];
+    for (int r = 0; r < R; ++r)
+        for (int l = 0; l < L; ++l) init[r][l] = s[packed_byte(r, l)];
+    __m256i v[R];
+    for (int r = 0; r < R; ++r) v[r] = _mm256_load_si256(reinterpret_cast<const __m256i *>(init[r]));
+    const __m256i vstep = _mm256_set1_epi64x(step), vm = _mm256_set1_epi64x(lcg::M), vff = _mm256_set1_epi32(0xFF),
+                  ones = _mm256_set1_epi8((char)0xFF);
+    uint64_t i = 0;
+    for (; i + W <= n; i += W) {
+        __m256i c[R / 2];
+        for (int k = 0; k < R / 2; ++k)
+            c[k] = _mm256_and_si256(_mm256_or_si256(v[2 * k], _mm256_slli_epi64(v[2 * k + 1], 32)), vff);
+        const __m256i state_bytes = _mm256_packus_epi16(_mm256_packus_epi32(c[0], c[1]), _mm256_packus_epi32(c[2], c[3]));
+        __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(buf + i));
+        d = _mm256_xor_si256(_mm256_xor_si256(d, state_bytes), ones); // keystream byte = ~low8(state)
+        _mm256_storeu_si256(reinterpret_cast<__m256i *>(buf + i), d);
+        for (int r = 0; r < R; ++r) {
+            const __m256i p = _mm256_mul_epu32(v[r], vstep);
+            const __m256i x = _mm256_add_epi64(_mm256_and_si256(p, vm), _mm256_srli_epi64(p, 31)); // < 2m, == p (mod m)
+            v[r] = _mm256_min_epu32(x, _mm256_sub_epi32(x, vm)); // canonical (x != m: m is prime, no zero factors)
+        }
+    }
+    if (i < n) { // ragged end: the next block's bytes, as many as are left
+        alignas(32) uint64_t last[R][L];
+        for (int r = 0; r < R; ++r) _mm256_store_si256(reinterpret_cast<__m256i *>(last[r]), v[r]);
+        uint8_t ks[W];
+        for (int r = 0; r < R; ++r)
+            for (int l = 0; l < L; ++l) ks[packed_byte(r, l)] = (uint8_t)~last[r][l];
+        for (int j = 0; i < n; ++i, ++j) buf[i] ^= ks[j];
+    }
+}
+
+__attribute__((target("avx512f,avx512bw"))) void span_avx512(uint8_t *buf, uint64_t n, uint32_t key_res, uint64_t pos)
+{
+    constexpr int W = 64, R = 8, L = 8;
+    uint32_t s[W];
+    s[0] = lcg::state_residue(key_res, pos);
+    for (int j = 1; j < W; ++j) s[j] = mulmod_fold(s[j - 1], lcg::A);
+    const uint32_t step = lcg::powmod(lcg::A, W);
+    alignas(64) uint64_t init[R][L];
+    for (int r = 0; r < R; ++r)
+        for (int l = 0; l < L; ++l) init[r][l] = s[packed_byte(r, l)];
+    __m512i v[R];
+    for (int r = 0; r < R; ++r) v[r] = _mm512_load_si512(init[r]);
+    const __m512i vstep = _mm512_set1_epi64(step), vm = _mm512_set1_epi64(lcg::M), vff = _mm512_set1_epi32(0xFF),
+                  ones = _mm512_set1_epi8((char)0xFF);
+    uint64_t i = 0;
+    for (; i + W <= n; i += W) {
+        __m512i c[R / 2];
+        for (int k = 0; k < R / 2; ++k)
+            c[k] = _mm512_and_si512(_mm512_or_si512(v[2 * k], _mm512_slli_epi64(v[2 * k + 1], 32)), vff);
+        const __m512i state_bytes = _mm512_packus_epi16(_mm512_packus_epi32(c[0], c[1]), _mm512_packus_epi32(c[2], c[3]));
+        __m512i d = _mm512_loadu_si512(buf + i);
+        d = _mm512_ternarylogic_epi64(d, state_bytes, ones, 0x96); // d ^ state ^ 0xFF
+        _mm512_storeu_si512(buf + i, d);
+        for (int r = 0; r < R; ++r) {
+            const __m512i p = _mm512_mul_epu32(v[r], vstep);
+            const __m512i x = _mm512_add_epi64(_mm512_and_si512(p, vm), _mm512_srli_epi64(p, 31));
+            v[r] = _mm512_min_epu32(x, _mm512_sub_epi32(x, vm));
+        }
+    }
+    if (i < n) {
+        alignas(64) uint64_t last[R][L];
+        for (int r = 0; r < R; ++r) _mm512_store_si512(last[r], v[r]);
+        uint8_t ks[W];
+        for (int r = 0; r < R; ++r)
+            for (int l = 0; l < L; ++l) ks[packed_byte(r, l)] = (uint8_t)~last[r][l];
+        for (int j = 0; i < n; ++i, ++j) buf[i] ^= ks[j];
+    }
+}
+
+using SpanFn = void (*)(uint8_t *, uint64_t, uint32_t, uint64_t);
+constexpr SpanFn kSpan[MODGPU_ISA_COUNT] = {span_generic, span_avx2, span_avx512};
+constexpr const char *kIsaName[MODGPU_ISA_COUNT] = {"generic", "avx2", "avx512"};
+
+bool isa_usable(int isa)
+{
+    switch (isa) {
+    case MODGPU_ISA_GENERIC: return true;
+    case MODGPU_ISA_AVX2: return __builtin_cpu_supports("avx2");
+    case MODGPU_ISA_AVX512: return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw");
+    default: return false;
+    }
+}
+
+int pick_isa()
+{
+    static const int v = [] {
+        if (const char *e = std::getenv("MODGPU_HOST_ISA"))
+            for (int i = 0; i < MODGPU_ISA_COUNT; ++i)
+                if (std::strcmp(e, kIsaName[i]) == 0 && isa_usable(i)) return i;
+        for (int i = MODGPU_ISA_COUNT - 1; i > 0; --i)
+            if (isa_usable(i)) return i;
+        return (int)MODGPU_ISA_GENERIC;
+    }();
+    return v;
+}
+
+// MODGPU_HOST_THREADS (read once): most host threads one call may use; 0 / unset = min(hardware, 32)
+unsigned max_threads()
+{
+    static const unsigned v = [] {
+        const char *e = std::getenv("MODGPU_HOST_THREADS");
+        int x = e ? std::atoi(e) : 0;
+        unsigned hw = std::thread::hardware_concurrency();
+        return x > 0 ? (unsigned)std::min(x, 256) : std::max(1u, std::min(hw, 32u));
+    }();
+    return v;
+}
+
+// Worker k of a call runs on the k-th CPU this process may use, skipping the one the calling thread is on
+// (MODGPU_HOST_SPREAD=0: leave placement to the scheduler).  Short-lived threads that the scheduler is left
+// to place can sit on one CPU for their whole life -- measured in a VM: 2 and 4 unpinned workers ran
+// serially (wall = CPU time), 8 spread out -- so each worker is given its own CPU up front.
+struct Spread {
+    std::vector<int> cpus;
+    Spread()
+    {
+        const char *e = std::getenv("MODGPU_HOST_SPREAD");
+        if (e && std::strcmp(e, "0") == 0) return;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) != 0) return;
+        for (int c = 0; c < CPU_SETSIZE; ++c)
+            if (CPU_ISSET(c, &set)) cpus.push_back(c);
+    }
+};
+void run_span_on(SpanFn span, int cpu, uint8_t *buf, uint64_t n, uint32_t key_res, uint64_t pos)
+{
+    if (cpu >= 0) {
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        CPU_SET(cpu, &one);
+        (void)sched_setaffinity(0, sizeof one, &one); // this worker thread only; best effort
+    }
+    span(buf, n, key_res, pos);
+}
+
 } // namespace
 
-void modgpu_scalar_cycle(uint8_t *buf, uint64_t n, int32_t key, uint64_t stream_off)
+int modgpu_scalar_isa() { return pick_isa(); }
+const char *modgpu_scalar_isa_name(int isa) { return isa >= 0 && isa < MODGPU_ISA_COUNT ? kIsaName[isa] : "?"; }
+bool modgpu_scalar_isa_usable(int isa) { return isa_usable(isa); }
+
+void modgpu_scalar_cycle(uint8_t *buf, uint64_t n, int32_t key, uint64_t stream_off, int isa)
 {
     const uint32_t key_res = lcg::key_residue(key);
     if (n == 0 || key_res == 0) return; // residue 0 sticks at m: keystream all zero (identity)
+    const SpanFn span = kSpan[isa >= 0 && isa < MODGPU_ISA_COUNT && isa_usable(isa) ? isa : pick_isa()];
     const uint64_t pos = stream_off % lcg::PERIOD;
-    constexpr uint64_t kSpanMin = 4ull << 20;
-    unsigned hw = std::thread::hardware_concurrency();
-    uint64_t threads = std::min<uint64_t>(std::max(1u, std::min(hw, 32u)), n / kSpanMin);
+    // a span is worth a thread from ~2 MiB (a few hundred microseconds of work against ~30 us to start one)
+    constexpr uint64_t kSpanMin = 2ull << 20;
+    uint64_t threads = std::min<uint64_t>(max_threads(), n / kSpanMin);
     if (threads <= 1) {
-        span_cycle(buf, n, key_res, pos);
+        span(buf, n, key_res, pos);
         return;
     }
     const uint64_t per = ((n + threads - 1) / threads + 63) & ~63ull;
+    static const Spread spread;
+    const int here = sched_getcpu();
+    size_t next_cpu = 0;
+    auto worker_cpu = [&]() -> int { // the next allowed CPU that is not the caller's; -1: leave it to the scheduler
+        if (spread.cpus.size() < threads) return -1;
+        if (spread.cpus[next_cpu % spread.cpus.size()] == here) ++next_cpu;
+        return spread.cpus[next_cpu++ % spread.cpus.size()];
+    };
     std::vector<std::thread> pool;
     try {
         for (uint64_t off = per; off < n; off += per)
-            pool.emplace_back(span_cycle, buf + off, std::min(per, n - off), key_res, pos + off % lcg::PERIOD);
+            pool.emplace_back(run_span_on, span, worker_cpu(), buf + off, std::min(per, n - off), key_res, pos + off % lcg::PERIOD);
     } catch (...) { // thread limit reached: finish what was not handed out on this thread
         uint64_t done = per * (pool.size() + 1);
-        if (done < n) span_cycle(buf + done, n - done, key_res, pos + done % lcg::PERIOD);
+        if (done < n) span(buf + done, n - done, key_res, pos + done % lcg::PERIOD);
     }
-    span_cycle(buf, std::min(per, n), key_res, pos);
+    span(buf, std::min(per, n), key_res, pos);
     for (auto &t : pool) t.join();
 }

@@ -1,6 +1,12 @@
-// scalar_path.h -- the library's own host loop (scalar_path.cpp); no HIP, no oracle.
+// scalar_path.h -- the library's own host loop (scalar_path.cpp).  No HIP.
 #pragma once
 #include <cstdint>
 
-// buf[j] ^= ks[stream_off + j] for j < n, in place, on the calling host (threads for >= 8 MiB).
-void modgpu_scalar_cycle(uint8_t *buf, uint64_t n, int32_t key, uint64_t stream_off);
+enum : int { MODGPU_ISA_AUTO = -1, MODGPU_ISA_GENERIC = 0, MODGPU_ISA_AVX2 = 1, MODGPU_ISA_AVX512 = 2, MODGPU_ISA_COUNT = 3 };
+
+// buf[j] ^= ks[stream_off + j].  isa: MODGPU_ISA_AUTO = the best body this CPU runs (latched once per process;
+// MODGPU_HOST_ISA overrides), or one body by name -- an unusable one falls back to the automatic choice.
+void modgpu_scalar_cycle(uint8_t *buf, uint64_t n, int32_t key, uint64_t stream_off, int isa = MODGPU_ISA_AUTO);
+int modgpu_scalar_isa();                       // the automatic choice
+const char *modgpu_scalar_isa_name(int isa);   // "generic" / "avx2" / "avx512"
+bool modgpu_scalar_isa_usable(int isa);

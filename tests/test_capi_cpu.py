@@ -21,15 +21,37 @@ def _declared(header):
 
 def test_header_symbols_all_exported(modgpu):
     assert _declared("modgpu.h") == set(modgpu.EXPORTS), _declared("modgpu.h") ^ set(modgpu.EXPORTS)
-    assert _declared("modgpu_testing.h") == set(modgpu.TESTING_EXPORTS)
+    hooks = set(modgpu.TESTING_EXPORTS) | set(modgpu.DEBUG_EXPORTS)
+    assert _declared("modgpu_testing.h") == hooks, _declared("modgpu_testing.h") ^ hooks
+    assert all(n.startswith("modgpu_debug_") for n in modgpu.DEBUG_EXPORTS)
+    assert not any(n.startswith("modgpu_debug_") for n in list(modgpu.EXPORTS) + list(modgpu.TESTING_EXPORTS))
     L = modgpu.lib()
+    assert modgpu.active_flavour() == "shipped" and not modgpu.testing_hooks()
     for name in list(modgpu.EXPORTS) + list(modgpu.TESTING_EXPORTS):
         assert getattr(L, name) is not None
-    assert L.modgpu_abi_version() == 3
-    # the library exports nothing else under its prefix (no stray test knobs in the ABI)
-    out = subprocess.run(["nm", "-D", "--defined-only", modgpu.lib_path()], capture_output=True, text=True).stdout
-    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("modgpu_")}
-    assert exported == set(modgpu.EXPORTS) | set(modgpu.TESTING_EXPORTS), exported ^ (set(modgpu.EXPORTS) | set(modgpu.TESTING_EXPORTS))
+    assert L.modgpu_abi_version() == 4
+
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+        return {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("modgpu_")}
+
+    # The shipped library exports exactly the ABI + the reporting hooks: no knob that changes how it launches or makes a
+    # call fail exists in it.  The testing flavour is the same plus the modgpu_debug_* hooks.
+    shipped = exported(modgpu.lib_path("shipped"))
+    assert shipped == set(modgpu.EXPORTS) | set(modgpu.TESTING_EXPORTS), shipped ^ (set(modgpu.EXPORTS) | set(modgpu.TESTING_EXPORTS))
+    assert not [n for n in shipped if "debug" in n]
+    assert exported(modgpu.lib_path("testing")) == shipped | set(modgpu.DEBUG_EXPORTS)
+    with pytest.raises(modgpu.ModGpuError):
+        modgpu.debug_set_launch("queue", 4)  # outside testing_flavour(): refused, the shipped library has no such hook
+    with modgpu.testing_flavour():
+        assert modgpu.testing_hooks() and modgpu.active_flavour() == "testing"
+        assert modgpu.kernel_source_hash() == _shipped_hash(modgpu)  # same device code in both
+        modgpu.debug_set_launch(None, 0)
+    assert modgpu.active_flavour() == "shipped"
+
+
+def _shipped_hash(modgpu):
+    return modgpu.capi._load("shipped").modgpu_kernel_source_hash().decode()
 
 
 def test_kernel_source_hash_matches_sources(modgpu):
@@ -149,16 +171,105 @@ def test_host_loop_matches_oracle_sizes_offsets_threads(modgpu, oracle):
 @needs_host_loop
 def test_auto_entry_point_uses_host_loop_without_gpu(modgpu, oracle):
     """BASELINE config 1 as worded: a 4 KiB blob on the CPU path, no GPU -- through the entry point
-    CEncryptionCycler::Cycle binds to."""
+    CEncryptionCycler::Cycle binds to.  Header-sized buffers are the host loop's by the size dispatch (SURVEY 8b);
+    larger ones end there only because no GPU can serve them."""
     if modgpu.device_count() > 0:
         pytest.skip("GPU present")
+    assert modgpu.min_gpu_bytes() == 128 << 10
     before = modgpu.path_stats()
     body = oracle.splitmix_bytes(4092, 0x4D6F64756C617465)
     got = modgpu.cycle_auto_host(body.copy(), modgpu.KEY_PS4)
     assert np.array_equal(got, oracle.cycle(body.copy(), oracle.KEY_PS4))
     after = modgpu.path_stats()
-    assert after["scalar_calls"] == before["scalar_calls"] + 1 and after["auto_fallbacks"] == before["auto_fallbacks"] + 1
+    assert after["scalar_calls"] == before["scalar_calls"] + 1 and after["auto_small"] == before["auto_small"] + 1
+    assert after["auto_fallbacks"] == before["auto_fallbacks"]
     assert after["scalar_bytes"] == before["scalar_bytes"] + 4092 and after["gpu_calls"] == before["gpu_calls"]
+    big = oracle.splitmix_bytes(300_001, 5)
+    assert np.array_equal(modgpu.cycle_auto_host(big.copy(), modgpu.KEY_PS3), oracle.cycle(big.copy(), oracle.KEY_PS3))
+    last = modgpu.path_stats()
+    assert last["auto_fallbacks"] == after["auto_fallbacks"] + 1 and last["auto_small"] == after["auto_small"]
+
+
+@pytest.mark.parametrize("setting,want", [("0", 0), ("4096", 4096), ("0x100000", 1 << 20), ("junk", 128 << 10), ("", 128 << 10)])
+def test_min_gpu_bytes_knob_is_latched_at_load(setting, want):
+    """MODGPU_MIN_GPU_BYTES (SURVEY 5 'min-size-for-GPU knob'): read once; n < value -> host loop in modgpu_cycle_auto_host
+    only.  On this GPU-less machine the route shows in the counters: below the threshold `auto_small`, at or above it
+    `auto_fallbacks` (the GPU was tried first)."""
+    code = ("import numpy as np, modulate_amd as M\n"
+            "print('MIN', M.min_gpu_bytes())\n"
+            "if M.device_count() == 0:\n"
+            "    for n in (4095, 4096, 4097):\n"
+            "        M.path_stats(reset=True); M.cycle_auto_host(np.zeros(n, np.uint8), M.KEY_PS4); st = M.path_stats()\n"
+            "        assert st['scalar_calls'] == 1 and st['auto_small'] == (1 if n < M.min_gpu_bytes() else 0), (n, st)\n"
+            "        assert st['auto_fallbacks'] == 1 - st['auto_small'], (n, st)\n"
+            "print('KNOB_OK')\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("MODGPU_MIN_GPU_BYTES", "MODGPU_REQUIRE_GPU")}
+    env.update(MODGPU_MIN_GPU_BYTES=setting, PYTHONPATH=ROOT, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "KNOB_OK" in r.stdout and f"MIN {want}\n" in r.stdout, r.stdout + r.stderr
+
+
+@needs_host_loop
+def test_every_host_loop_body_matches_oracle_and_golden(modgpu, oracle, golden):
+    """generic / avx2 / avx512 bodies of the host loop (scalar_path.cpp), each against the oracle over block
+    boundaries of every body (16 / 32 / 64 bytes), misaligned views, period wrap and 64-bit offsets, and against
+    the reference's own keystream digests."""
+    ran = []
+    for isa in ("generic", "avx2", "avx512"):
+        probe = np.zeros(1, np.uint8)
+        try:
+            modgpu.cycle_scalar_host_isa(probe, 1, isa)
+        except modgpu.ModGpuError as e:
+            assert e.code == 1  # this CPU does not run that body
+            continue
+        ran.append(isa)
+        for n in (0, 1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 4092, 100_003):
+            for key in (0x90CFC0AB, 0xC64EED30, 1, 0xFFFFFFFF, 0, 0x80000001):
+                for off in (0, 7, oracle.PERIOD - 40, (1 << 32) - 1, (1 << 64) - 70000):
+                    pt = oracle.splitmix_bytes(n + 8, n + 1)
+                    got = pt.copy()
+                    modgpu.cycle_scalar_host_isa(got[3:3 + n], key, isa, off)
+                    want = pt.copy()
+                    oracle.cycle_at(want[3:3 + n], key, off)
+                    assert np.array_equal(got, want), (isa, n, hex(key), off)
+        for ks in golden["keystream"]:
+            z = np.zeros(1 << 20, np.uint8)
+            modgpu.cycle_scalar_host_isa(z, ks["key"], isa)
+            assert z[:64].tobytes().hex() == ks["first64"] and oracle.fnv1a64(z) == int(ks["fnv_1m"], 16), (isa, hex(ks["key"]))
+    assert "generic" in ran and modgpu.host_loop_isa() == ran[-1]  # the automatic choice is the widest body the CPU runs
+    with pytest.raises(modgpu.ModGpuError):
+        modgpu.cycle_scalar_host_isa(np.zeros(4, np.uint8), 1, "sse9")
+
+
+def test_numa_topology_reader_on_a_fake_sysfs(modgpu, tmp_path):
+    """The sysfs reader behind modgpu_host_alloc_near / _alloc_parts and the worker placement, pointed at
+    a fake two-socket tree."""
+    sysfs = tmp_path / "sys"
+    for bdf, node in (("0000:05:00.0", "0"), ("0000:85:00.0", "1"), ("0000:c5:00.0", "-1")):
+        d = sysfs / "bus" / "pci" / "devices" / bdf
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(node + "\n")
+    for node, cpus in ((0, "0-3,128-131\n"), (1, "64-66,70,  200-201\n")):
+        d = sysfs / "devices" / "system" / "node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus)
+    assert modgpu.numa_probe(str(sysfs), "0000:05:00.0") == (0, [0, 1, 2, 3, 128, 129, 130, 131])
+    assert modgpu.numa_probe(str(sysfs), "0000:85:00.0") == (1, [64, 65, 66, 70, 200, 201])
+    assert modgpu.numa_probe(str(sysfs), "0000:c5:00.0") == (-1, [])   # the kernel's own "no node"
+    assert modgpu.numa_probe(str(sysfs), "0000:ff:00.0") == (-1, [])   # no such device
+    assert modgpu.numa_probe(str(tmp_path / "nowhere"), "0000:05:00.0") == (-1, [])
+    assert modgpu.numa_probe(str(sysfs), "0000:05:00.0", max_cpus=3) == (0, [0, 1, 2])
+
+
+def test_placed_host_memory_without_gpu_is_plain_memory(modgpu):
+    if modgpu.device_count() > 0:
+        pytest.skip("GPU present")
+    assert modgpu.device_numa_node(0) == -1
+    for pb in (modgpu.PinnedBuffer(300_000, near_device=0), modgpu.PinnedBuffer(300_000, parts=[100_000, 0, 200_000], n_devices=8)):
+        assert not pb.pinned
+        pb.array[:] = 3
+        assert int(pb.array.sum()) == 900_000
+        pb.free()
 
 
 def test_require_gpu_forbids_the_host_loop(modgpu):

@@ -8,6 +8,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import modulate_amd as M  # noqa: E402
+M.use_testing_flavour()  # modgpu_debug_set_launch exists only in libmodgpu_testing.so
 
 cap = 1 << 30
 if len(sys.argv) > 1:  # force a launch shape: small | large | queue

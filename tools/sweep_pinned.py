@@ -14,6 +14,7 @@ CHILD = r'''
 import sys, time, numpy as np
 sys.path.insert(0, %r)
 import modulate_amd as M
+M.use_testing_flavour()  # the route / shape selectors exist only in libmodgpu_testing.so
 what = sys.argv[1]
 def timeit(fn, n):
     fn()
