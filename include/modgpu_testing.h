@@ -68,9 +68,9 @@ int modgpu_testing_hooks(void);
 
 /* ---- below: libmodgpu_testing.so only ------------------------------------------------------------------ */
 
-/* Eager work-queue launches draw their ticket pair from the first `lines` lines of the ring (1..256; 0 = all
- * 256).  With one line every second launch in flight finds the ring busy: the collision the gating exists for
- * becomes certain instead of a 1-in-256 event. */
+/* Eager work-queue launches draw their ticket pair from the first `lines` lines of the ring (1..4096; 0 = all
+ * 4096).  With one line every second launch in flight finds the ring busy: the collision the gating exists for
+ * becomes certain instead of a 1-in-4096 event. */
 void modgpu_debug_set_queue_ring(uint32_t lines);
 
 /* Forces the launch shape of every later launch in this process (-1 = by size, the default) and

@@ -106,7 +106,9 @@ FLAVOURS = {"shipped": "libmodgpu.so", "testing": "libmodgpu_testing.so"}
 
 
 def lib_path(flavour="shipped"):
-    return os.path.join(_HERE, FLAVOURS[flavour])
+    # MODGPU_LIB: another build of the same sources stands in for both flavours (the sanitizer builds of
+    # `make sanitize-lib`, which carry the hooks; tests/test_sanitizers.py)
+    return os.environ.get("MODGPU_LIB") or os.path.join(_HERE, FLAVOURS[flavour])
 
 
 _libs = {}
@@ -243,7 +245,7 @@ def debug_inject_failures(count):
 
 
 def debug_set_queue_ring(lines=0):
-    """Test hook: eager work-queue launches draw ticket pairs from the first `lines` ring lines only (0 = all 256)."""
+    """Test hook: eager work-queue launches draw ticket pairs from the first `lines` ring lines only (0 = all 4096)."""
     _debug_lib().modgpu_debug_set_queue_ring(lines)
 
 

@@ -1,0 +1,64 @@
+// shim_launch.cpp -- the launch side of the CPU stand-in (hip_shim/hip/hip_runtime.h): cycle_kernel.h's interface
+// implemented on the host.  A "launch" is queued on the stream's thread and does, from the launch PLAN alone
+// (CycleArgs: head / body / tail pointers, the three base states, `lead`), what the kernel would do to the same
+// bytes -- with the product's own Park-Miller arithmetic (lcg.h), byte by byte.  So the sanitizer runs check the
+// host's planning (splits, jump-ahead states, alignment lead) as well as its memory and thread discipline.
+// The work-queue shape's ticket pair is emulated: taken at the start of the launch, cleaned and signed off at its
+// end, and a launch that finds its pair taken counts a collision.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <thread>
+
+#include "../cycle_kernel.h"
+#include "../lcg.h"
+
+namespace {
+std::atomic<unsigned long long> g_collisions{0}, g_launches[kCycleVariants] = {};
+
+struct Launch { CycleArgs a; int variant; };
+
+void span(uint8_t *p, uint64_t n, uint32_t state) // state = canonical state of p[0]
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        p[i] ^= (uint8_t)~state;
+        state = lcg::mulmod(state, lcg::A);
+    }
+}
+
+void run(void *arg)
+{
+    Launch *l = static_cast<Launch *>(arg);
+    const CycleArgs &a = l->a;
+    const bool queue = l->variant == CYCLE_QUEUE && a.queue;
+    if (queue) {
+        uint32_t expect = 0;
+        if (!std::atomic_ref<uint32_t>(a.queue[0]).compare_exchange_strong(expect, 1u)) g_collisions.fetch_add(1); // another launch holds this pair
+        std::this_thread::sleep_for(std::chrono::microseconds(200)); // a launch lasts a while: overlaps become likely
+    }
+    span(a.head_ptr, a.head_n, a.base_head);
+    // base_body is the state `lead` bytes before the body
+    span(static_cast<uint8_t *>(a.body), a.body_words * lcg::WORD, lcg::mulmod(a.base_body, lcg::powmod(lcg::A, a.lead)));
+    span(a.tail_ptr, a.tail_n, a.base_tail);
+    if (queue) {
+        std::atomic_ref<uint32_t>(a.queue[0]).store(0u);
+        if (a.queue_done) std::atomic_ref<uint32_t>(*a.queue_done).store(a.queue_seq, std::memory_order_release);
+    }
+    g_launches[l->variant].fetch_add(1);
+    delete l;
+}
+} // namespace
+
+uint32_t modgpu_variant_chunk_bytes(int variant) { return variant == CYCLE_QUEUE ? 65536u : variant == CYCLE_LARGE ? 131072u : 4096u; }
+uint32_t modgpu_variant_block(int variant) { return variant == CYCLE_SMALL ? 256u : 1024u; }
+const char *modgpu_variant_kernel_name(int variant) { return variant == CYCLE_QUEUE ? "shim queue" : variant == CYCLE_LARGE ? "shim large" : "shim small"; }
+
+hipError_t modgpu_launch_cycle(const CycleArgs &a, int variant, uint32_t, hipStream_t stream)
+{
+    shim::enqueue(stream, run, new Launch{a, variant});
+    return hipSuccess;
+}
+
+extern "C" unsigned long long modgpu_shim_pair_collisions(void) { return g_collisions.load(); }
+extern "C" unsigned long long modgpu_shim_launches(int variant) { return variant >= 0 && variant < kCycleVariants ? g_launches[variant].load() : 0; }

@@ -1,10 +1,29 @@
-// modbench_main.cpp -- the bench.py measurement without Python: C ABI only (include/modgpu.h).
+// modbench_main.cpp -- measurements without Python: C ABI only (include/modgpu.h).
+//
 //   modbench [part_bytes=4294967296] [steps=20] [warmup=3] [device=0]
-// A step is one encrypt pass + one decrypt pass over an HBM-resident part; prints payload GB/s and
-// the HBM read+write GB/s of the mean launch (HIP events on the launch stream, inside the library).
+//       bench.py's measurement: a step is one encrypt pass + one decrypt pass over an HBM-resident part; prints payload
+//       GB/s and the HBM read+write GB/s of the mean launch (HIP events on the launch stream, inside the library).
+//   modbench --parts N [--devices d0,d1,...] [--part-bytes B] [--steps S] [--warmup W]
+//       ONE process driving N resident parts, part i on devices[i mod len] (BASELINE config 3's shape), through
+//       modgpu_cycle_parts_device: aggregate GB/s of the whole job by the wall clock, pass 1 checked against the
+//       library's own closed form on windows, an even number of passes against the input.
+//   modbench --hostcall
+//       modgpu_cycle_host (kernel) against modgpu_cycle_scalar_host (host loop) per call from 64 B to 2 MiB, and the
+//       crossover MODGPU_MIN_GPU_BYTES should sit at; per-core and all-core GB/s of every host-loop body.
+//   modbench --files DIR [--bytes B]...
+//       the file routes (modgpu_cycle_file / _file_to_host / _host_to_file) beside their two ceilings: the same
+//       pread / pwrite schedule with the cipher skipped (I/O only) and the cipher with the I/O skipped (GPU only).
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/modgpu.h"
@@ -12,34 +31,312 @@
 
 #define TRY( x ) do { int rc_ = ( x ); if( rc_ != MODGPU_OK ) { std::printf( "modgpu error %d: %s\n", rc_, modgpu_last_error() ); return 1; } } while( 0 )
 
-int main( int argc, char** argv )
+namespace
 {
-    const uint64_t n = argc > 1 ? std::strtoull( argv[ 1 ], nullptr, 0 ) : ( 1ull << 32 );
-    const int steps = argc > 2 ? std::atoi( argv[ 2 ] ) : 20;
-    const int warmup = argc > 3 ? std::atoi( argv[ 3 ] ) : 3;
-    const int device = argc > 4 ? std::atoi( argv[ 4 ] ) : 0;
-    if( modgpu_device_count() < 1 ) { std::printf( "no HIP device\n" ); return 1; }
+const int32_t kKey = (int32_t)MODGPU_KEY_PS4;
+double Now() { return std::chrono::duration< double >( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
+
+std::vector< unsigned char > Tile( size_t n, unsigned int seed )
+{
+    std::vector< unsigned char > t( n );
+    unsigned int x = seed;
+    for( auto& b : t ) { x = x * 1664525u + 1013904223u; b = (unsigned char)( x >> 24 ); }
+    return t;
+}
+
+int Classic( uint64_t n, int steps, int warmup, int device )
+{
     void* part = nullptr;
     TRY( modgpu_alloc( &part, n, device ) );
-    std::vector< unsigned char > tile( 64u << 20 );
-    unsigned int x = 12345;
-    for( auto& b : tile ) { x = x * 1664525u + 1013904223u; b = (unsigned char)( x >> 24 ); }
+    const std::vector< unsigned char > tile = Tile( 64u << 20, 12345 );
     for( uint64_t off = 0; off < n; off += tile.size() )
         TRY( modgpu_h2d( (char*)part + off, tile.data(), std::min< uint64_t >( tile.size(), n - off ), device ) );
-    const int32_t key = (int32_t)MODGPU_KEY_PS4;
     float ms = 0.f;
-    if( warmup > 0 ) TRY( modgpu_time_cycle_device( part, n, key, 0, device, nullptr, 2 * warmup, &ms ) );
+    if( warmup > 0 ) TRY( modgpu_time_cycle_device( part, n, kKey, 0, device, nullptr, 2 * warmup, &ms ) );
     TRY( modgpu_sync( device, nullptr ) );
-    auto t0 = std::chrono::steady_clock::now();
-    TRY( modgpu_time_cycle_device( part, n, key, 0, device, nullptr, 2 * steps, &ms ) );
+    const double t0 = Now();
+    TRY( modgpu_time_cycle_device( part, n, kKey, 0, device, nullptr, 2 * steps, &ms ) );
     TRY( modgpu_sync( device, nullptr ) );
-    double dt = std::chrono::duration< double >( std::chrono::steady_clock::now() - t0 ).count();
+    const double dt = Now() - t0;
     std::vector< unsigned char > back( 1u << 20 );
     TRY( modgpu_d2h( back.data(), part, std::min< uint64_t >( back.size(), n ), device ) );
-    bool restored = std::equal( back.begin(), back.begin() + (long)std::min< uint64_t >( back.size(), n ), tile.begin() );
+    const bool restored = std::equal( back.begin(), back.begin() + (long)std::min< uint64_t >( back.size(), n ), tile.begin() );
     std::printf( "{\"part_bytes\": %llu, \"steps\": %d, \"payload_GBps\": %.1f, \"ms_per_launch\": %.4f, \"hbm_read_write_GBps\": %.1f, \"frac_of_8TBps\": %.4f, \"even_passes_restore_input\": %s}\n",
                  (unsigned long long)n, steps, 2.0 * steps * (double)n / dt / 1e9, ms, 2.0 * (double)n / ( ms * 1e-3 ) / 1e9,
                  2.0 * (double)n / ( ms * 1e-3 ) / 8e12, restored ? "true" : "false" );
     TRY( modgpu_free( part, device ) );
     return restored ? 0 : 2;
+}
+
+// ---- --parts: one process, N resident parts, N devices --------------------------------------------------------------
+int Parts( int nParts, std::vector< int > devices, uint64_t n, int steps, int warmup )
+{
+    const int avail = modgpu_device_count();
+    if( devices.empty() ) for( int d = 0; d < std::min( nParts, avail ); ++d ) devices.push_back( d );
+    std::vector< void* > parts( (size_t)nParts, nullptr );
+    std::vector< uint64_t > sizes( (size_t)nParts, n );
+    std::vector< int > where( (size_t)nParts );
+    const std::vector< unsigned char > tile = Tile( 64u << 20, 777 );
+    for( int i = 0; i < nParts; ++i )
+    {
+        where[ i ] = devices[ (size_t)i % devices.size() ];
+        TRY( modgpu_alloc( &parts[ i ], n, where[ i ] ) );
+        for( uint64_t off = 0; off < n; off += tile.size() )
+            TRY( modgpu_h2d( (char*)parts[ i ] + off, tile.data(), std::min< uint64_t >( tile.size(), n - off ), where[ i ] ) );
+    }
+    auto pass = [ & ]() { return modgpu_cycle_parts_device( parts.data(), sizes.data(), where.data(), nParts, kKey ); };
+    // pass 1 of the warm-up doubles as the check: ciphertext ^ plaintext == low8(state) ^ 0xFF on windows of every part
+    TRY( pass() );
+    bool ok = true;
+    std::vector< unsigned char > win( 4096 );
+    for( int i = 0; i < nParts && ok; ++i )
+        for( uint64_t off : { (uint64_t)0, n / 2 + 13, n - std::min< uint64_t >( n, win.size() ) } )
+        {
+            const uint64_t len = std::min< uint64_t >( win.size(), n - off );
+            TRY( modgpu_d2h( win.data(), (char*)parts[ i ] + off, len, where[ i ] ) );
+            for( uint64_t j = 0; j < len; j += 97 )
+                ok = ok && (unsigned char)( win[ j ] ^ tile[ ( off + j ) % tile.size() ] ) == (unsigned char)( ~modgpu_state_at( kKey, off + j ) & 0xFF );
+        }
+    TRY( pass() );
+    for( int w = 1; w < warmup; ++w ) { TRY( pass() ); TRY( pass() ); }
+    const double t0 = Now();
+    for( int s = 0; s < steps; ++s ) { TRY( pass() ); TRY( pass() ); }
+    const double dt = Now() - t0;
+    for( int i = 0; i < nParts && ok; ++i )
+    {
+        TRY( modgpu_d2h( win.data(), (char*)parts[ i ] + ( n > win.size() ? n - win.size() : 0 ), std::min< uint64_t >( win.size(), n ), where[ i ] ) );
+        const uint64_t off = n > win.size() ? n - win.size() : 0;
+        for( uint64_t j = 0; j < std::min< uint64_t >( win.size(), n ); ++j ) ok = ok && win[ j ] == tile[ ( off + j ) % tile.size() ];
+    }
+    std::string devs;
+    for( size_t i = 0; i < devices.size(); ++i ) devs += ( i ? "," : "" ) + std::to_string( devices[ i ] );
+    std::printf( "{\"mode\": \"parts\", \"parts\": %d, \"devices\": [%s], \"logical_devices_visible\": %d, \"part_bytes\": %llu, \"steps\": %d, "
+                 "\"aggregate_payload_GBps\": %.1f, \"aggregate_hbm_read_write_GBps\": %.1f, \"ms_per_pass_over_all_parts\": %.4f, \"bit_exact_windows\": %s}\n",
+                 nParts, devs.c_str(), avail, (unsigned long long)n, steps, 2.0 * steps * nParts * (double)n / dt / 1e9,
+                 4.0 * steps * nParts * (double)n / dt / 1e9, dt / ( 2.0 * steps ) * 1e3, ok ? "true" : "false" );
+    for( int i = 0; i < nParts; ++i ) TRY( modgpu_free( parts[ i ], where[ i ] ) );
+    return ok ? 0 : 2;
+}
+
+// ---- --hostcall: kernel vs host loop per call ------------------------------------------------------------------------
+template < typename F > double MedianUs( F&& call, int reps )
+{
+    std::vector< double > t( (size_t)reps );
+    for( int i = 0; i < reps; ++i )
+    {
+        const double t0 = Now();
+        call();
+        t[ i ] = ( Now() - t0 ) * 1e6;
+    }
+    std::sort( t.begin(), t.end() );
+    return t[ t.size() / 2 ];
+}
+
+int HostCall()
+{
+    const bool gpu = modgpu_device_count() > 0;
+    std::printf( "== per-call latency, caller-owned pageable host buffer (what CEncryptionCycler::Cycle gets): median of N calls\n" );
+    std::printf( "   host loop body: %s   |   MODGPU_MIN_GPU_BYTES as latched: %llu   |   GPU %s\n", modgpu_host_loop_isa(),
+                 (unsigned long long)modgpu_min_gpu_bytes(), gpu ? "present" : "ABSENT (host-loop column only)" );
+    std::printf( "   %10s  %14s  %14s  %10s\n", "bytes", "kernel (us)", "host loop (us)", "faster" );
+    uint64_t crossover = 0;
+    bool crossed = false;
+    for( uint64_t n : { 64ull, 256ull, 1024ull, 4092ull, 8192ull, 16384ull, 32768ull, 49152ull, 65536ull, 98304ull, 131072ull, 196608ull, 262144ull, 393216ull, 524288ull, 1048576ull, 2097152ull } )
+    {
+        std::vector< unsigned char > buf = Tile( n, (unsigned int)n );
+        const int reps = n <= 65536 ? 2000 : 400;
+        double g = -1;
+        if( gpu )
+        {
+            for( int i = 0; i < 20; ++i ) TRY( modgpu_cycle_host( buf.data(), n, kKey, 0, 0 ) );
+            g = MedianUs( [ & ] { (void)modgpu_cycle_host( buf.data(), n, kKey, 0, 0 ); }, reps );
+        }
+        for( int i = 0; i < 20; ++i ) TRY( modgpu_cycle_scalar_host( buf.data(), n, kKey, 0 ) );
+        const double h = MedianUs( [ & ] { (void)modgpu_cycle_scalar_host( buf.data(), n, kKey, 0 ); }, reps );
+        if( gpu && !crossed && g < h ) { crossover = n; crossed = true; }
+        if( gpu && g >= h ) crossed = false; // keep the LAST size from which the kernel stays ahead
+        std::printf( "   %10llu  %14.1f  %14.1f  %10s\n", (unsigned long long)n, g, h, !gpu ? "-" : ( g < h ? "kernel" : "host loop" ) );
+    }
+    if( gpu ) std::printf( "   kernel ahead from %llu bytes up\n", (unsigned long long)crossover );
+    std::printf( "== host loop throughput by body (in place, warm; one thread below 4 MiB, MODGPU_HOST_THREADS / all cores above)\n" );
+    for( const char* isa : { "generic", "avx2", "avx512" } )
+    {
+        std::vector< unsigned char > probe( 64 );
+        if( modgpu_cycle_scalar_host_isa( probe.data(), probe.size(), kKey, 0, isa ) != MODGPU_OK ) { std::printf( "   %-8s not available on this CPU\n", isa ); continue; }
+        for( uint64_t n : { 1ull << 20, 3ull << 20, 256ull << 20, 1ull << 30 } )
+        {
+            std::vector< unsigned char > buf( n, 0x5A );
+            (void)modgpu_cycle_scalar_host_isa( buf.data(), n, kKey, 0, isa );
+            const int reps = n <= ( 3ull << 20 ) ? 50 : 3;
+            const double us = MedianUs( [ & ] { (void)modgpu_cycle_scalar_host_isa( buf.data(), n, kKey, 0, isa ); }, reps );
+            std::printf( "   %-8s %6llu MiB  %9.1f us  %7.2f GB/s  (%s)\n", isa, (unsigned long long)( n >> 20 ), us, n / us / 1e3,
+                         n < ( 4ull << 20 ) ? "1 thread" : "threads" );
+        }
+    }
+    return 0;
+}
+
+// ---- --files: the file routes beside their ceilings ---------------------------------------------------------------------
+// the library's chunking of a stream of n bytes (host_stream.cpp: stream_impl) at its default tunables
+void Schedule( uint64_t n, uint64_t* chunk, int* pipes )
+{
+    const uint64_t cap = 8ull << 20;
+    uint64_t c = n <= ( 4ull << 20 ) ? std::max< uint64_t >( n, 1ull << 20 ) : std::min< uint64_t >( cap, std::max< uint64_t >( 4ull << 20, ( ( n >> 4 ) + 0xFFFFF ) & ~0xFFFFFull ) );
+    c = std::min( c, cap );
+    const uint64_t chunks = ( n + c - 1 ) / c;
+    *chunk = c;
+    *pipes = (int)std::min< uint64_t >( 8, ( chunks + 1 ) / 2 );
+}
+
+bool ReadAll( int fd, void* p, uint64_t len, uint64_t off )
+{
+    for( uint64_t done = 0; done < len; )
+    {
+        ssize_t r = ::pread( fd, (char*)p + done, len - done, (off_t)( off + done ) );
+        if( r <= 0 ) return false;
+        done += (uint64_t)r;
+    }
+    return true;
+}
+bool WriteAll( int fd, const void* p, uint64_t len, uint64_t off )
+{
+    for( uint64_t done = 0; done < len; )
+    {
+        ssize_t r = ::pwrite( fd, (const char*)p + done, len - done, (off_t)( off + done ) );
+        if( r <= 0 ) return false;
+        done += (uint64_t)r;
+    }
+    return true;
+}
+
+// I/O only: `pipes` threads, thread p takes chunks p, p+pipes, ...; src/dst are a file (fd >= 0) or memory
+double IoOnly( int inFd, const unsigned char* inMem, int outFd, unsigned char* outMem, uint64_t n, bool preallocate )
+{
+    uint64_t chunk;
+    int pipes;
+    Schedule( n, &chunk, &pipes );
+    if( preallocate && outFd >= 0 ) (void)::posix_fallocate( outFd, 0, (off_t)n );
+    const uint64_t chunks = ( n + chunk - 1 ) / chunk;
+    const double t0 = Now();
+    std::vector< std::thread > pool;
+    for( int p = 0; p < pipes; ++p )
+        pool.emplace_back( [ =, &chunk ] {
+            void* slot = nullptr;
+            if( modgpu_host_alloc( &slot, chunk ) != MODGPU_OK ) return;
+            for( uint64_t c = (uint64_t)p; c < chunks; c += (uint64_t)pipes )
+            {
+                const uint64_t off = c * chunk, len = std::min( chunk, n - off );
+                const void* from = inMem ? (const void*)( inMem + off ) : slot;
+                if( !inMem ) ReadAll( inFd, slot, len, off );
+                if( outMem ) { if( from != outMem + off ) std::memcpy( outMem + off, from, len ); }
+                else WriteAll( outFd, from, len, off );
+            }
+            modgpu_host_free( slot );
+        } );
+    for( auto& t : pool ) t.join();
+    return Now() - t0;
+}
+
+int Files( const std::string& dir, std::vector< uint64_t > sizes )
+{
+    if( sizes.empty() ) sizes = { 64ull << 20, 411ull * 1000 * 1000, 1ull << 32 };
+    std::printf( "== file routes beside their ceilings (dir %s; GB/s of payload; best of 3)\n", dir.c_str() );
+    std::printf( "   I/O only = the same chunks and threads, pread/pwrite (or memcpy) without the cipher; GPU only = modgpu_cycle_host on page-locked memory of the same size\n" );
+    for( uint64_t n : sizes )
+    {
+        const std::string src = dir + "/modbench_src.bin", dst = dir + "/modbench_dst.bin";
+        void* pinned = nullptr;
+        TRY( modgpu_host_alloc( &pinned, n ) );
+        unsigned char* mem = static_cast< unsigned char* >( pinned );
+        {
+            const std::vector< unsigned char > tile = Tile( 16u << 20, 99 );
+            for( uint64_t off = 0; off < n; off += tile.size() ) std::memcpy( mem + off, tile.data(), std::min< uint64_t >( tile.size(), n - off ) );
+            int fd = ::open( src.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644 );
+            if( fd < 0 || !WriteAll( fd, mem, n, 0 ) ) { std::printf( "cannot write %s\n", src.c_str() ); return 1; }
+            ::close( fd );
+        }
+        auto best = []( auto&& run ) { double b = 1e30; for( int i = 0; i < 3; ++i ) b = std::min( b, run() ); return b; };
+        uint64_t chunk;
+        int pipes;
+        Schedule( n, &chunk, &pipes );
+        std::printf( "-- %7.0f MiB  (%d pipelines x %llu MiB chunks)\n", n / 1048576.0, pipes, (unsigned long long)( chunk >> 20 ) );
+        const double gpuOnly = best( [ & ] { const double t0 = Now(); (void)modgpu_cycle_host( mem, n, kKey, 0, 0 ); return Now() - t0; } );
+        std::printf( "   %-44s %8.2f GB/s\n", "GPU only (pinned memory in place)", n / gpuOnly / 1e9 );
+        struct Row { const char* name; double io, ioPre, route; };
+        std::vector< Row > rows;
+        { // file -> file
+            Row r{ "modgpu_cycle_file (file -> file)", 0, 0, 0 };
+            r.io = best( [ & ] { int i = ::open( src.c_str(), O_RDONLY ), o = ::open( dst.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644 ); double t = IoOnly( i, nullptr, o, nullptr, n, false ); ::close( i ); ::close( o ); return t; } );
+            r.ioPre = best( [ & ] { int i = ::open( src.c_str(), O_RDONLY ), o = ::open( dst.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644 ); double t = IoOnly( i, nullptr, o, nullptr, n, true ); ::close( i ); ::close( o ); return t; } );
+            r.route = best( [ & ] { const double t0 = Now(); (void)modgpu_cycle_file( src.c_str(), dst.c_str(), kKey, 0, 0 ); return Now() - t0; } );
+            rows.push_back( r );
+        }
+        { // file -> pinned host
+            Row r{ "modgpu_cycle_file_to_host (file -> pinned)", 0, 0, 0 };
+            r.io = r.ioPre = best( [ & ] { int i = ::open( src.c_str(), O_RDONLY ); double t = IoOnly( i, nullptr, -1, mem, n, false ); ::close( i ); return t; } );
+            r.route = best( [ & ] { const double t0 = Now(); (void)modgpu_cycle_file_to_host( src.c_str(), 0, mem, n, kKey, 0, 0 ); return Now() - t0; } );
+            rows.push_back( r );
+        }
+        { // pinned host -> file
+            Row r{ "modgpu_cycle_host_to_file (pinned -> file)", 0, 0, 0 };
+            r.io = best( [ & ] { int o = ::open( dst.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644 ); double t = IoOnly( -1, mem, o, nullptr, n, false ); ::close( o ); return t; } );
+            r.ioPre = best( [ & ] { int o = ::open( dst.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644 ); double t = IoOnly( -1, mem, o, nullptr, n, true ); ::close( o ); return t; } );
+            r.route = best( [ & ] { const double t0 = Now(); (void)modgpu_cycle_host_to_file( mem, n, dst.c_str(), kKey, 0, 0 ); return Now() - t0; } );
+            rows.push_back( r );
+        }
+        for( const Row& r : rows )
+        {
+            const double ceiling = std::max( std::min( r.io, r.ioPre ), gpuOnly ); // the slower of the two stages bounds an overlapped pipeline
+            std::printf( "   %-44s %8.2f GB/s   I/O only %7.2f (fallocate first: %7.2f)   -> %3.0f %% of its ceiling (%.2f GB/s)\n", r.name, n / r.route / 1e9,
+                         n / r.io / 1e9, n / r.ioPre / 1e9, 100.0 * ceiling / r.route, n / ceiling / 1e9 );
+        }
+        ::unlink( src.c_str() );
+        ::unlink( dst.c_str() );
+        TRY( modgpu_host_free( pinned ) );
+    }
+    return 0;
+}
+
+std::vector< int > IntList( const char* s )
+{
+    std::vector< int > v;
+    for( const char* p = s; *p; )
+    {
+        v.push_back( std::atoi( p ) );
+        while( *p && *p != ',' ) ++p;
+        if( *p == ',' ) ++p;
+    }
+    return v;
+}
+} // namespace
+
+int main( int argc, char** argv )
+{
+    std::string mode = "classic", dir = "/dev/shm";
+    int nParts = 0, steps = 20, warmup = 3;
+    uint64_t partBytes = 1ull << 32;
+    std::vector< int > devices;
+    std::vector< uint64_t > fileSizes;
+    std::vector< const char* > positional;
+    for( int i = 1; i < argc; ++i )
+    {
+        const std::string a = argv[ i ];
+        auto next = [ & ]() -> const char* { return i + 1 < argc ? argv[ ++i ] : ""; };
+        if( a == "--parts" ) { mode = "parts"; nParts = std::atoi( next() ); }
+        else if( a == "--devices" ) devices = IntList( next() );
+        else if( a == "--part-bytes" ) partBytes = std::strtoull( next(), nullptr, 0 );
+        else if( a == "--steps" ) steps = std::atoi( next() );
+        else if( a == "--warmup" ) warmup = std::atoi( next() );
+        else if( a == "--hostcall" ) mode = "hostcall";
+        else if( a == "--files" ) { mode = "files"; dir = next(); }
+        else if( a == "--bytes" ) fileSizes.push_back( std::strtoull( next(), nullptr, 0 ) );
+        else positional.push_back( argv[ i ] );
+    }
+    if( mode == "hostcall" ) return HostCall();
+    if( modgpu_device_count() < 1 ) { std::printf( "no HIP device\n" ); return 1; }
+    if( mode == "parts" ) return nParts > 0 ? Parts( nParts, devices, partBytes, steps, std::max( warmup, 1 ) ) : 1;
+    if( mode == "files" ) return Files( dir, fileSizes );
+    const uint64_t n = positional.size() > 0 ? std::strtoull( positional[ 0 ], nullptr, 0 ) : ( 1ull << 32 );
+    return Classic( n, positional.size() > 1 ? std::atoi( positional[ 1 ] ) : 20, positional.size() > 2 ? std::atoi( positional[ 2 ] ) : 3,
+                    positional.size() > 3 ? std::atoi( positional[ 3 ] ) : 0 );
 }

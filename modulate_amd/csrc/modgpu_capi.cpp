@@ -226,12 +226,12 @@ uint32_t large_grid()
 //   * a launch that is being captured into a hipGraph is baked into the graph together with its pair, and may
 //     be replayed at any later time, so it never draws from the ring: it gets a line of its own from a
 //     separate grow-only pool that is never handed out again (pool empty: static shape).
-constexpr uint32_t kQueueRing = 256;  // eager lines
+constexpr uint32_t kQueueRing = 4096; // eager lines: more than any caller keeps in flight (a launch that finds none free still has the static shape)
 constexpr uint32_t kGraphPool = 1024; // lines owned by captured launches, for the life of the process
 struct QueueRing {
     std::mutex mu;
     std::atomic<uint32_t *> base{nullptr}; // device: (kQueueRing + kGraphPool) lines of 16 words, all zero between launches
-    volatile uint32_t *done = nullptr;     // host-coherent pinned memory: one word per ring line, written by the kernel
+    uint32_t *done = nullptr;              // host-coherent pinned memory: one word per ring line, written by the kernel
     uint32_t *done_dev = nullptr;          // the same words as the device addresses them
     uint32_t issued[kQueueRing] = {};      // sequence number given to the line's latest user   (under mu)
     uint32_t next = 0;                     // where the search for a free line starts           (under mu)
@@ -318,7 +318,8 @@ QueuePair queue_pair(hipStream_t stream)
     const uint32_t lines = std::max(1u, std::min(ring_lines(), kQueueRing));
     for (uint32_t k = 0; k < lines; ++k) {
         const uint32_t line = (r.next + k) % lines;
-        if (r.done[line] != r.issued[line]) continue; // its latest user has not signed off yet
+        // (an acquire load of a word the GPU writes: what follows is ordered behind seeing the sign-off)
+        if (__atomic_load_n(&r.done[line], __ATOMIC_ACQUIRE) != r.issued[line]) continue; // its latest user has not signed off yet
         r.next = line + 1;
         q.pair = base + (size_t)line * 16;
         q.done = r.done_dev + line;

@@ -1,0 +1,236 @@
+"""Cases for the sanitizer builds of libmodgpu's OWN host code (`make -C modulate_amd/csrc sanitize-lib`).
+
+Not collected by a plain `pytest tests/`: tests/test_sanitizers.py runs this file in a child process with
+MODGPU_LIB pointing at _san/libmodgpu_asan.so or _san/libmodgpu_tsan.so and the matching runtime preloaded.
+Those builds link hip_shim/ instead of the HIP runtime: streams are real threads, a "launch" executes the launch
+plan with the product's own arithmetic on the CPU, eight devices exist.  What runs under the sanitizers is
+therefore exactly the code that cannot be sanitized on the GPU: launch planning, the ticket ring, the host-range
+table, the staging pipelines' retire / refill state machine and their error paths, per-device contexts, worker
+threads, per-thread error strings.  Every case also compares bytes with the oracle (the plan is checked too)."""
+import ctypes
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import modulate_amd as M
+from oracle import oracle as O
+
+pytestmark = pytest.mark.skipif(not os.environ.get("MODGPU_LIB"), reason="runs only against a sanitizer build (tests/test_sanitizers.py)")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L = M.lib()
+    assert M.testing_hooks() and M.device_count() == 8, "expects the shim build with MODGPU_SHIM_DEVICES=8"
+    L.modgpu_shim_pair_collisions.restype = ctypes.c_ulonglong
+    L.modgpu_shim_launches.restype = ctypes.c_ulonglong
+    return L
+
+
+@pytest.fixture()
+def hooks(lib):
+    with M.testing_flavour():
+        try:
+            yield M
+        finally:
+            M.debug_set_launch(None, 0)
+            M.debug_set_pinned_mode(0)
+            M.debug_set_staged_mode(0)
+            M.debug_set_queue_ring(0)
+            M.debug_inject_failures(0)
+
+
+def want(pt, key, off=0):
+    w = pt.copy()
+    O.cycle_at(w, key, off)
+    return w
+
+
+def test_launch_plan_sizes_alignments_shapes(hooks):
+    """head / body / tail split, alignment lead and jump-ahead states of every launch shape."""
+    cap = 400_000
+    d = M.DeviceBuffer(cap + 256)
+    rng = np.random.default_rng(1)
+    for shape in (None, "small", "large", "queue"):
+        M.debug_set_launch(shape, 3 if shape else 0)
+        for n in (0, 1, 15, 16, 17, 4095, 4096, 4097, 65536 - 16, 65536 + 16, 131072 + 5, 300_001):
+            for al in (0, 1, 4, 15):
+                key = [0x90CFC0AB, 0xC64EED30, 1, 0, 0x7FFFFFFF][(n + al) % 5]
+                so = [0, O.PERIOD - 7, (1 << 40) + 3][(n + al) % 3]
+                whole = rng.integers(0, 256, size=n + 128, dtype=np.uint8)
+                d.upload(whole)
+                d.cycle(key, n=n, offset=64 + al, stream_off=so)
+                d.sync()
+                w = whole.copy()
+                O.cycle_at(w[64 + al:64 + al + n], key, so)
+                assert np.array_equal(d.download(n + 128), w), (shape, n, al)
+    d.free()
+
+
+def test_staged_pipelines_and_routes(hooks):
+    """Pageable buffers through 8 pipelines x 2 slots (MODGPU_HOST_CHUNK_MB=1: many chunks on few MiB), both forms of
+    the staged route, pinned caller memory through both pinned routes, registered memory, placed memory."""
+    assert M.host_tunables()["chunk_bytes"] == 1 << 20
+    for n in (1, 4097, (1 << 20) + 1, (3 << 20) - 1, (17 << 20) + 5):
+        pt = O.splitmix_bytes(n + 16, n)
+        for mode in (0, 1):
+            M.debug_set_staged_mode(mode)
+            buf = pt.copy()
+            M.cycle_host(buf[9:9 + n], M.KEY_PS3, stream_off=77)
+            w = pt.copy()
+            O.cycle_at(w[9:9 + n], M.KEY_PS3, 77)
+            assert np.array_equal(buf, w), (n, mode)
+    M.debug_set_staged_mode(0)
+    n = (5 << 20) + 3
+    pt = O.splitmix_bytes(n, 5)
+    for pb in (M.PinnedBuffer(n + 64), M.PinnedBuffer(n + 64, near_device=3), M.PinnedBuffer(n + 64, parts=[n // 2, n + 64 - n // 2], n_devices=8)):
+        assert pb.pinned
+        for mode in (1, 2):
+            M.debug_set_pinned_mode(mode)
+            pb.array[:] = 0xEE
+            pb.array[13:13 + n] = pt
+            M.cycle_host(pb.array[13:13 + n], M.KEY_PS4, device=5)
+            assert np.array_equal(pb.array[13:13 + n], want(pt, M.KEY_PS4)) and (pb.array[:13] == 0xEE).all() and (pb.array[13 + n:] == 0xEE).all()
+        pb.free()
+    M.debug_set_pinned_mode(0)
+    buf = pt.copy()
+    M.host_register(buf)
+    M.cycle_host(buf, M.KEY_PS4)
+    M.host_unregister(buf)
+    assert np.array_equal(buf, want(pt, M.KEY_PS4))
+    assert M.lib().modgpu_host_free(buf.ctypes.data) == 1 and M.lib().modgpu_host_unregister(buf.ctypes.data) == 1
+
+
+def test_file_routes_and_their_error_paths(hooks, tmp_path):
+    for n in (0, 1, (2 << 20) + 3, (9 << 20) + 11):
+        pt = O.splitmix_bytes(n, n + 3)
+        src, dst = tmp_path / f"p{n}", tmp_path / f"c{n}"
+        pt.tofile(src)
+        M.cycle_file(src, dst, M.KEY_PS4)
+        assert np.array_equal(np.fromfile(dst, dtype=np.uint8), want(pt, M.KEY_PS4) if n else pt)
+        M.cycle_file(dst, dst, M.KEY_PS4)
+        assert np.array_equal(np.fromfile(dst, dtype=np.uint8), pt)
+        assert np.array_equal(M.cycle_file_to_host(src, n, M.KEY_PS4), want(pt, M.KEY_PS4) if n else pt)
+        pb = M.PinnedBuffer(n + 1)
+        M.cycle_file_to_host(src, n, M.KEY_PS4, out=pb.array[:n])
+        M.cycle_host_to_file(pb.array[:n], dst, M.KEY_PS4)
+        assert np.array_equal(np.fromfile(dst, dtype=np.uint8), pt)
+        pb.free()
+    for call in (lambda: M.cycle_file(tmp_path / "missing", tmp_path / "x", M.KEY_PS4),
+                 lambda: M.cycle_file_to_host(tmp_path / f"p{(9 << 20) + 11}", (9 << 20) + 99, M.KEY_PS4),  # short file: workers drain and stop
+                 lambda: M.cycle_host_to_file(np.zeros(10, np.uint8), tmp_path / "no" / "such" / "dir", M.KEY_PS4)):
+        with pytest.raises(M.ModGpuError) as e:
+            call()
+        assert e.value.code == 5 and str(e.value)
+
+
+def test_eight_workers_and_per_thread_errors(hooks):
+    sizes = [0, 1, 4096, 1_000_003, (3 << 20) + 5, 77, (2 << 20) + 1, 0, 500_000, 16, (1 << 20) - 3]
+    for n_dev in (8, 3, 0):
+        parts = [O.splitmix_bytes(s, 100 + i) for i, s in enumerate(sizes)]
+        ws = [want(p, M.KEY_PS3) for p in parts]
+        M.cycle_parts_host(parts, M.KEY_PS3, n_dev)
+        assert all(np.array_equal(g, w) for g, w in zip(parts, ws)), n_dev
+    bufs = [M.DeviceBuffer(200_000 + 16 * i, device=i) for i in range(8)]
+    for b in bufs:
+        b.upload(np.zeros(b.nbytes, np.uint8))
+    M.cycle_parts_device(bufs, M.KEY_PS4)
+    for b in bufs:
+        assert np.array_equal(b.download(), O.keystream(M.KEY_PS4, b.nbytes))
+        b.free()
+    # every thread keeps its own error text; the counters are shared
+    errs = {}
+
+    def worker(i):
+        try:
+            M.cycle_host(np.zeros(10, np.uint8), M.KEY_PS4, device=8 + i)
+        except M.ModGpuError as e:
+            errs[i] = (e.code, str(e))
+        pt = O.splitmix_bytes(300_000 + i, i)
+        assert np.array_equal(M.cycle_host(pt.copy(), M.KEY_PS4, device=i), want(pt, M.KEY_PS4))
+        M.path_stats()
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert len(errs) == 8 and all(c == 1 and "out of range" in s for c, s in errs.values())
+
+
+def test_injected_failures_and_the_second_engine(hooks):
+    assert not M.gpu_required()
+    pt = O.splitmix_bytes(3_000_001, 8)
+    M.path_stats(reset=True)
+    M.debug_inject_failures(2)
+    with pytest.raises(M.ModGpuError) as e:
+        M.cycle_host(pt.copy(), M.KEY_PS4)  # the GPU-only entry point never falls back
+    assert e.value.code == 3
+    buf = pt.copy()
+    M.cycle_auto_host(buf, M.KEY_PS4)  # injected failure -> the host loop finishes the call
+    assert np.array_equal(buf, want(pt, M.KEY_PS4))
+    M.cycle_auto_host(buf, M.KEY_PS4)  # no injection left: the (shim) GPU serves it
+    assert np.array_equal(buf, pt)
+    small = O.splitmix_bytes(4092, 2)
+    assert np.array_equal(M.cycle_auto_host(small.copy(), M.KEY_PS4), want(small, M.KEY_PS4))
+    st = M.path_stats()
+    assert st["auto_fallbacks"] == 1 and st["auto_small"] == 1 and st["scalar_calls"] == 2 and st["gpu_calls"] == 1, st
+
+
+def test_ticket_ring_under_concurrent_streams(hooks, lib):
+    """Two host threads, each with its own stream, launching queue-shape work at the same time.  Ring of ONE line: the
+    launches must never hold the pair together (the shim counts a launch that finds its pair taken)."""
+    for ring in (1, 2, 0):
+        M.debug_set_queue_ring(ring)
+        M.debug_set_launch("queue", 4)
+        before = lib.modgpu_shim_pair_collisions()
+        q0 = M.queue_stats()
+        n = 200_000
+        out = {}
+
+        def run(i):
+            st = ctypes.c_void_p()
+            assert lib.modgpu_shim_stream_create(ctypes.byref(st)) == 0
+            pt = O.splitmix_bytes(n + 32, 50 + i)
+            d = M.DeviceBuffer(n + 32)
+            d.upload(pt)
+            for _ in range(41):
+                d.cycle(M.KEY_PS4, n=n, offset=7 + i, stream_off=i, stream=st.value)
+            d.sync(stream=st.value)
+            w = pt.copy()
+            O.cycle_at(w[7 + i:7 + i + n], M.KEY_PS4, i)
+            out[i] = np.array_equal(d.download(), w)
+            d.free()
+            assert lib.modgpu_shim_stream_destroy(st) == 0
+
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        q1 = M.queue_stats()
+        assert out == {0: True, 1: True}, ring
+        assert lib.modgpu_shim_pair_collisions() == before, "a ticket pair was handed to two overlapping launches"
+        assert q1["eager"] + q1["busy_fallbacks"] - q0["eager"] - q0["busy_fallbacks"] == 82
+        if ring == 1:
+            assert q1["busy_fallbacks"] > q0["busy_fallbacks"]
+
+
+def test_calls_leave_the_callers_device_alone(hooks, lib):
+    """an entry point called with an explicit device must not leave the calling thread's current HIP device
+    switched (in a torch process that would silently move torch's work to another GPU)."""
+    assert lib.modgpu_shim_set_device(5) == 0
+    pt = O.splitmix_bytes(100_000, 1)
+    M.cycle_host(pt.copy(), M.KEY_PS4, device=2)
+    M.cycle_host(O.splitmix_bytes((3 << 20) + 1, 2), M.KEY_PS4, device=7)  # worker threads
+    d = M.DeviceBuffer(70_000, device=3)
+    d.upload(pt[:70_000])
+    d.cycle(M.KEY_PS4)
+    d.sync()
+    M.cycle_parts_device([d], M.KEY_PS4)
+    assert np.array_equal(d.download(), pt[:70_000])
+    d.free()
+    M.cycle_parts_host([pt.copy(), pt.copy(), pt.copy()], M.KEY_PS4, 3)
+    assert lib.modgpu_shim_get_device() == 5
+    b = M.DeviceBuffer(16)  # device=-1: the calling thread's current device is the one used
+    b.free()
+    assert lib.modgpu_shim_get_device() == 5
+    assert lib.modgpu_shim_set_device(0) == 0

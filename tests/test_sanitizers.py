@@ -31,3 +31,38 @@ def test_host_logic_under_asan_ubsan():
                        env=env, capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "passed" in r.stdout
+
+
+def _san_lib_cases(preload, lib, extra_env):
+    from oracle import oracle as O
+    O.build(ref=False)  # here, not in the child: the compiler must not run under a preloaded sanitizer runtime
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "modulate_amd", "csrc"), "sanitize-lib"])
+    env = dict(os.environ, LD_PRELOAD=preload, MODGPU_LIB=os.path.join(ROOT, "modulate_amd", "_san", lib),
+               MODGPU_SHIM_DEVICES="8", MODGPU_HOST_CHUNK_MB="1", MODGPU_REQUIRE_GPU="0", **extra_env)
+    for k in ("MODGPU_HOST_PIPES", "MODGPU_HOST_ZEROCOPY_KB", "MODGPU_MIN_GPU_BYTES", "MODGPU_DEVICE_ALIAS"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "san_lib_cases.py"), "-x", "-q", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0 and "7 passed" in r.stdout, r.stdout[-4000:] + r.stderr[-4000:]
+
+
+def test_library_host_code_under_asan_ubsan():
+    """libmodgpu's own threaded host code (modgpu_capi.cpp, host_stream.cpp) built against hip_shim/ -- a CPU
+    stand-in for the HIP runtime whose streams are real threads -- with ASan + UBSan, driven by tests/san_lib_cases.py:
+    launch planning at every shape, staged pipelines and both route forms, pinned / registered / placed memory, file routes
+    and their error paths, eight workers on eight devices, failure injection, the ticket ring under two concurrent streams."""
+    asan, ubsan = _runtime("libasan.so"), _runtime("libubsan.so")
+    if not asan or not ubsan:
+        pytest.skip("gcc sanitizer runtimes not installed")
+    _san_lib_cases(f"{asan}:{ubsan}", "libmodgpu_asan.so",
+                   {"ASAN_OPTIONS": "detect_leaks=0:abort_on_error=1", "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1"})
+
+
+def test_library_host_code_under_tsan():
+    """The same cases under ThreadSanitizer: the staging pipelines' retire / refill state machine, the ring's bookkeeping, the
+    host-range table and the shared counters, with worker threads and stream threads really running concurrently."""
+    tsan = _runtime("libtsan.so")
+    if not tsan:
+        pytest.skip("gcc ThreadSanitizer runtime not installed")
+    _san_lib_cases(tsan, "libmodgpu_tsan.so",
+                   {"TSAN_OPTIONS": f"halt_on_error=1 second_deadlock_stack=1 suppressions={os.path.join(ROOT, 'tests', 'tsan.supp')}"})
