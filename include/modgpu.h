@@ -42,7 +42,8 @@
  *
  * Environment (each read once, when first needed):
  *     MODGPU_REQUIRE_GPU=1       no host loop anywhere (see above)
- *     MODGPU_MIN_GPU_BYTES=n     modgpu_cycle_auto_host's size threshold (default 131072; 0 = always the GPU)
+ *     MODGPU_MIN_GPU_BYTES=n     modgpu_cycle_auto_host's size threshold (default 16 MiB, the measured crossover
+ *                                against one host thread; 0 = always the GPU)
  *     MODGPU_HOST_ISA=name       host-loop body: generic | avx2 | avx512 (default: the best the CPU runs)
  *     MODGPU_HOST_THREADS=n      most host threads one host-loop call may use (default min(cores, 32))
  *     MODGPU_DEVICE_ALIAS=n      see modgpu_device_count

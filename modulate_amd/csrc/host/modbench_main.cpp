@@ -10,6 +10,8 @@
 //   modbench --hostcall
 //       modgpu_cycle_host (kernel) against modgpu_cycle_scalar_host (host loop) per call from 64 B to 2 MiB, and the
 //       crossover MODGPU_MIN_GPU_BYTES should sit at; per-core and all-core GB/s of every host-loop body.
+//   modbench --alloc
+//       what the part buffer costs: modgpu_host_alloc against modgpu_host_alloc_parts, and the kernel's rate on each.
 //   modbench --files DIR [--bytes B]...
 //       the file routes (modgpu_cycle_file / _file_to_host / _host_to_file) beside their two ceilings: the same
 //       pread / pwrite schedule with the cipher skipped (I/O only) and the cipher with the I/O skipped (GPU only).
@@ -234,9 +236,9 @@ double IoOnly( int inFd, const unsigned char* inMem, int outFd, unsigned char* o
     uint64_t chunk;
     int pipes;
     Schedule( n, &chunk, &pipes );
-    if( preallocate && outFd >= 0 ) (void)::posix_fallocate( outFd, 0, (off_t)n );
     const uint64_t chunks = ( n + chunk - 1 ) / chunk;
     const double t0 = Now();
+    if( preallocate && outFd >= 0 ) (void)::posix_fallocate( outFd, 0, (off_t)n ); // inside the timed region: it is part of the job
     std::vector< std::thread > pool;
     for( int p = 0; p < pipes; ++p )
         pool.emplace_back( [ =, &chunk ] {
@@ -316,6 +318,36 @@ int Files( const std::string& dir, std::vector< uint64_t > sizes )
     return 0;
 }
 
+// ---- --alloc: what the part buffer costs to get ----------------------------------------------------------------------------
+int Alloc( uint64_t n, int nParts )
+{
+    std::printf( "== page-locked host memory for a %.0f MiB part buffer in %d parts: allocate, free (seconds; best of 3)\n", n / 1048576.0, nParts );
+    auto best = []( auto&& run ) { double b = 1e30; for( int i = 0; i < 3; ++i ) b = std::min( b, run() ); return b; };
+    void* p = nullptr;
+    double tFree = 0;
+    const double a = best( [ & ] { const double t0 = Now(); (void)modgpu_host_alloc( &p, n ); const double t = Now() - t0; const double f0 = Now(); (void)modgpu_host_free( p ); tFree = Now() - f0; return t; } );
+    std::printf( "   modgpu_host_alloc       (hipHostMalloc)                                  %.3f s  (%.1f GB/s)   free %.3f s\n", a, n / a / 1e9, tFree );
+    std::vector< uint64_t > sizes( (size_t)nParts, n / (uint64_t)nParts );
+    sizes.back() += n - sizes[ 0 ] * (uint64_t)nParts;
+    const double b = best( [ & ] { const double t0 = Now(); (void)modgpu_host_alloc_parts( &p, sizes.data(), nParts, 0 ); const double t = Now() - t0; const double f0 = Now(); (void)modgpu_host_free( p ); tFree = Now() - f0; return t; } );
+    std::printf( "   modgpu_host_alloc_parts (mmap, per-part policy, parallel first touch, lock) %.3f s  (%.1f GB/s)   free %.3f s\n", b, n / b / 1e9, tFree );
+    TRY( modgpu_host_alloc_parts( &p, sizes.data(), nParts, 0 ) );
+    std::printf( "   placed memory is page-locked: %s; GPU 0 is on NUMA node %d\n", modgpu_host_is_pinned( p, n ) ? "yes" : "NO", modgpu_device_numa_node( 0 ) );
+    // is locked-in-place memory as good a target for the kernel across PCIe as hipHostMalloc'ed memory?
+    for( int which = 0; which < 2; ++which )
+    {
+        void* q = nullptr;
+        if( which == 0 ) TRY( modgpu_host_alloc( &q, n ) ); else q = p;
+        std::memset( q, 0x11, n );
+        (void)modgpu_cycle_host( static_cast< uint8_t* >( q ), n, kKey, 0, 0 );
+        const double t = best( [ & ] { const double t0 = Now(); (void)modgpu_cycle_host( static_cast< uint8_t* >( q ), n, kKey, 0, 0 ); return Now() - t0; } );
+        std::printf( "   modgpu_cycle_host in place on %-24s %.2f GB/s\n", which == 0 ? "modgpu_host_alloc memory" : "placed memory", n / t / 1e9 );
+        if( which == 0 ) TRY( modgpu_host_free( q ) );
+    }
+    TRY( modgpu_host_free( p ) );
+    return 0;
+}
+
 std::vector< int > IntList( const char* s )
 {
     std::vector< int > v;
@@ -347,6 +379,7 @@ int main( int argc, char** argv )
         else if( a == "--steps" ) steps = std::atoi( next() );
         else if( a == "--warmup" ) warmup = std::atoi( next() );
         else if( a == "--hostcall" ) mode = "hostcall";
+        else if( a == "--alloc" ) { mode = "alloc"; partBytes = 3291444381ull; nParts = 8; }
         else if( a == "--files" ) { mode = "files"; dir = next(); }
         else if( a == "--bytes" ) fileSizes.push_back( std::strtoull( next(), nullptr, 0 ) );
         else positional.push_back( argv[ i ] );
@@ -355,6 +388,7 @@ int main( int argc, char** argv )
     if( modgpu_device_count() < 1 ) { std::printf( "no HIP device\n" ); return 1; }
     if( mode == "parts" ) return nParts > 0 ? Parts( nParts, devices, partBytes, steps, std::max( warmup, 1 ) ) : 1;
     if( mode == "files" ) return Files( dir, fileSizes );
+    if( mode == "alloc" ) return Alloc( partBytes, nParts > 0 ? nParts : 8 );
     const uint64_t n = positional.size() > 0 ? std::strtoull( positional[ 0 ], nullptr, 0 ) : ( 1ull << 32 );
     return Classic( n, positional.size() > 1 ? std::atoi( positional[ 1 ] ) : 20, positional.size() > 2 ? std::atoi( positional[ 2 ] ) : 3,
                     positional.size() > 3 ? std::atoi( positional[ 3 ] ) : 0 );

@@ -114,14 +114,15 @@ int staging_reserve(Staging &s, int first, int count, uint64_t need, bool want_d
     return MODGPU_OK;
 }
 
-int fill_slot(const Endpoint &src, uint8_t *pinned, uint64_t off, uint64_t len)
+// `len` bytes at offset `off` of the source -> to[0 .. len)
+int fill_slot(const Endpoint &src, uint8_t *to, uint64_t off, uint64_t len)
 {
     if (src.mem) {
-        std::memcpy(pinned, src.mem + off, len);
+        std::memcpy(to, src.mem + off, len);
         return MODGPU_OK;
     }
     for (uint64_t done = 0; done < len;) {
-        ssize_t r = ::pread(src.fd, pinned + done, len - done, (off_t)(src.base + off + done));
+        ssize_t r = ::pread(src.fd, to + done, len - done, (off_t)(src.base + off + done));
         if (r < 0 && errno == EINTR) continue;
         if (r < 0) return fail_io("pread");
         if (r == 0) return fail(MODGPU_ERR_IO, "pread: unexpected end of file");
@@ -151,6 +152,8 @@ struct Job {
     int32_t key;
     uint64_t stream_off;
     bool slot_kernel = false; // staged chunks are cycled in their pinned slot across PCIe (no DMA, no device slot)
+    bool in_dst = false;      // file -> page-locked caller memory: pread lands in the destination itself, which the kernel then
+                              // cycles where it lies across PCIe (no slot, no DMA, no copy)
     std::atomic<bool> touched{false};
 };
 
@@ -171,7 +174,7 @@ int run_pipe(Staging &s, int slot0, int ring, Job &j, uint64_t first, uint64_t s
             uint64_t off, len;
             span(first + (i - ring) * stride, &off, &len);
             HIP_TRY(hipStreamSynchronize(s.stream[slot]));
-            if (!dst_direct) {
+            if (!dst_direct && !j.in_dst) {
                 j.touched.store(true, std::memory_order_relaxed);
                 int rc = drain_slot(j.dst, s.pinned[slot], off, len);
                 if (rc) return rc;
@@ -180,6 +183,14 @@ int run_pipe(Staging &s, int slot0, int ring, Job &j, uint64_t first, uint64_t s
         if (i < mine) {
             uint64_t off, len;
             span(first + i * stride, &off, &len);
+            if (j.in_dst) {
+                j.touched.store(true, std::memory_order_relaxed);
+                int rc = fill_slot(j.src, j.dst.mem + off, off, len);
+                if (rc) return rc;
+                void *mapped = nullptr;
+                HIP_TRY(hipHostGetDevicePointer(&mapped, j.dst.mem + off, 0));
+                return cycle_device_impl(mapped, len, j.key, j.stream_off + off, s.stream[slot], /*over_pcie=*/true);
+            }
             if (j.slot_kernel) { // neither side is pinned caller memory: the slot itself is the device-visible copy
                 int rc = fill_slot(j.src, s.pinned[slot], off, len);
                 if (rc) return rc;
@@ -287,7 +298,12 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     chunk = std::min<uint64_t>(chunk, kChunk);
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
     Job job{src, dst, n, chunk, key, stream_off};
+    // Default routes (profiles/r03_file_routes.txt): pageable memory and files are copied / read into a pinned slot and
+    // cycled there across PCIe; a file that ends in page-locked caller memory is read straight into that memory and cycled
+    // where it lies; page-locked caller memory that ends in a file is DMA'd.  (Testing flavour, staged mode 1: the DMA
+    // form -- H2D, kernel in HBM, D2H -- of the first two.)
     job.slot_kernel = !src_direct && !dst_direct && staged_mode() != 1;
+    job.in_dst = dst_direct && !src.mem && !identity && staged_mode() != 1;
     int pipes, ring;
     if (all_direct && src.mem && dst.mem) { // no host work at all: one thread keeps a ring of slots busy
         pipes = 1;
@@ -296,7 +312,10 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
         pipes = (int)std::min<uint64_t>((uint64_t)kPipes, (n_chunks + 1) / 2); // a pipeline is worth >= 2 chunks
         ring = 2;
     }
-    rc = staging_reserve(s, 0, pipes * ring, chunk, !job.slot_kernel, !(src_direct && dst_direct));
+    // a destination file gets its blocks before eight threads write into it at once (tmpfs and most file systems
+    // allocate under one lock: parallel extending writes serialise there)
+    if (dst.fd >= 0 && n >= (8ull << 20)) (void)::posix_fallocate(dst.fd, (off_t)dst.base, (off_t)n);
+    rc = staging_reserve(s, 0, pipes * ring, chunk, !job.slot_kernel && !job.in_dst, !(src_direct && dst_direct) && !job.in_dst);
     if (rc) return rc;
 
     if (pipes <= 1) {

@@ -53,9 +53,12 @@ int fail_io(const char *what)
 }
 
 // MODGPU_MIN_GPU_BYTES (read once): modgpu_cycle_auto_host serves buffers shorter than this with the host loop.
-// Default: the measured crossover on the MI355X node (profiles/r03_small_call_crossover.txt) -- a kernel launch
-// plus the wait for it costs ~14 us before the first byte moves, the host loop does a header in less.
-constexpr uint64_t kMinGpuBytesDefault = 128ull << 10;
+// Default: the crossover measured on the MI355X node between the kernel route and ONE host thread
+// (profiles/r03_small_call_crossover.txt).  A kernel launch plus the wait for it costs ~14 us before the first byte
+// moves and the data crosses PCIe twice; the AVX-512 host loop does 17 GB/s per core on that node's EPYC 9575F:
+// a 4 KiB header takes 0.4 us against 16, 512 KiB (the largest header the reference can write, CArk.cpp:911-912)
+// 30 us against 67, and the kernel route first gets ahead of one thread between 16 and 32 MiB.
+constexpr uint64_t kMinGpuBytesDefault = 16ull << 20;
 uint64_t min_gpu_bytes()
 {
     static const uint64_t v = [] {
@@ -307,7 +310,7 @@ QueuePair queue_pair(hipStream_t stream)
     }
     std::lock_guard<std::mutex> lock(r.mu);
     if (cap != hipStreamCaptureStatusNone) { // the graph keeps its line for good
-        if (r.graph_used >= kGraphPool) {
+        if (r.graph_used >= kGraphPool - 1) { // (the last line belongs to prepare_device's empty launch)
             g_queue_graph_full.fetch_add(1, std::memory_order_relaxed);
             return q;
         }
@@ -458,10 +461,18 @@ void prepare_device()
     hipStream_t st = nullptr;
     uint8_t *scratch = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&scratch), 4096) == hipSuccess) {
-        (void)queue_ring_create(g_queue_ring[dev], st);
-        (void)cycle_device_impl(scratch, 4096, 1, 0, st); // any launch loads the code object all three shapes live in
+        // one empty launch of every shape: the code object is loaded and each kernel has been through its first dispatch
+        // (the first launch of a kernel costs tens of microseconds more than the following ones).  The queue shape's
+        // empty launch counts itself in and out on the pool's last line, which is never handed out.
+        if (queue_ring_create(g_queue_ring[dev], st)) {
+            CycleArgs a{};
+            a.body = a.head_ptr = a.tail_ptr = scratch;
+            a.base_head = a.base_body = a.base_tail = 1;
+            a.stride_mul2 = 2;
+            a.queue = g_queue_ring[dev].base.load(std::memory_order_acquire) + (size_t)(kQueueRing + kGraphPool - 1) * 16;
+            for (int v = 0; v < kCycleVariants; ++v) (void)modgpu_launch_cycle(a, v, 1, st);
+        }
         (void)hipStreamSynchronize(st);
-        g_stats.gpu_launches.fetch_sub(1, std::memory_order_relaxed); // not a launch anybody asked for
     }
     (void)hipGetLastError();
     if (scratch) (void)hipFree(scratch);
@@ -735,6 +746,10 @@ int modgpu_host_free(void *host_ptr)
     });
 }
 
+namespace {
+constexpr int kPrefaultThreads = 8; // first touch of a placed allocation (numa_place.h: prefault)
+}
+
 int modgpu_host_alloc_parts(void **host_ptr, const uint64_t *sizes, int n_parts, int n_devices)
 {
     return guarded([&]() -> int {
@@ -753,7 +768,9 @@ int modgpu_host_alloc_parts(void **host_ptr, const uint64_t *sizes, int n_parts,
         // (a page shared by two parts stays with the default policy); pages are faulted in by the registration below
         uint64_t off = 0;
         for (int i = 0; i < n_parts; ++i) {
-            (void)numa::prefer_node(static_cast<uint8_t *>(p) + off, sizes[i], device_numa_node(i % n_devices));
+            const int node = device_numa_node(i % n_devices);
+            (void)numa::prefer_node(static_cast<uint8_t *>(p) + off, sizes[i], node);
+            numa::prefault(static_cast<uint8_t *>(p) + off, sizes[i], kPrefaultThreads, "/sys", node);
             off += sizes[i];
         }
         bool pinned = hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess;
@@ -779,6 +796,7 @@ int modgpu_host_alloc_near(void **host_ptr, uint64_t n, int device)
         void *p = numa::reserve(bytes);
         if (!p) return fail(MODGPU_ERR_INVALID, "out of host memory");
         (void)numa::prefer_node(p, bytes, device_numa_node(device));
+        numa::prefault(p, bytes, kPrefaultThreads, "/sys", device_numa_node(device));
         bool pinned = hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess;
         if (!pinned) (void)hipGetLastError();
         {

@@ -9,7 +9,9 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <fstream>
+#include <thread>
 
 namespace modgpu {
 namespace numa {
@@ -95,6 +97,27 @@ int prefer_node(void *p, size_t bytes, int node)
     mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
     constexpr int kMpolPreferred = 1;
     return (int)::syscall(SYS_mbind, (void *)lo, (unsigned long)(hi - lo), kMpolPreferred, mask, 1024ul + 1, 0u) == 0 ? 0 : -1;
+}
+
+void prefault(void *p, size_t bytes, int threads, const std::string &sysfs, int node)
+{
+    if (!p || bytes == 0) return;
+    const size_t page = (size_t)::sysconf(_SC_PAGESIZE);
+    const size_t per_thread_min = 64u << 20;
+    size_t n = std::min<size_t>((size_t)std::max(threads, 1), (bytes + per_thread_min - 1) / per_thread_min);
+    const size_t per = ((bytes + n - 1) / n + page - 1) & ~(page - 1);
+    auto touch = [=](size_t lo, size_t hi, bool own_thread) {
+        if (own_thread && node >= 0) (void)run_on_node(sysfs, node);
+        volatile unsigned char *b = static_cast<volatile unsigned char *>(p);
+        for (size_t o = lo; o < hi; o += page) b[o] = 0;
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (size_t t = 1; t < n; ++t) pool.emplace_back(touch, t * per, std::min(bytes, (t + 1) * per), true);
+    } catch (...) { // thread limit: the rest is touched below, by the lock call itself
+    }
+    touch(0, std::min(bytes, per), false);
+    for (auto &t : pool) t.join();
 }
 
 int run_on_node(const std::string &sysfs, int node)

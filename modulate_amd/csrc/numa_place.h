@@ -31,6 +31,11 @@ void release(void *p, size_t bytes);
 // Binds the whole pages inside [p, p + bytes) to `node`; call before the pages are first touched.  0 = done.
 int prefer_node(void *p, size_t bytes, int node);
 
+// Touches every page of [p, p + bytes) from up to `threads` threads (each on `node`'s CPUs when node >= 0), so that a
+// page-locking call that follows finds the pages present: first touch -- allocating and zeroing -- is what page-locking
+// a fresh range spends its time on, and it parallelises; the locking itself does not.
+void prefault(void *p, size_t bytes, int threads, const std::string &sysfs, int node);
+
 // Restricts the calling thread to the CPUs of `node` (sched_setaffinity).  0 = done, -1 = left as it was.
 int run_on_node(const std::string &sysfs, int node);
 

@@ -175,7 +175,7 @@ def test_auto_entry_point_uses_host_loop_without_gpu(modgpu, oracle):
     larger ones end there only because no GPU can serve them."""
     if modgpu.device_count() > 0:
         pytest.skip("GPU present")
-    assert modgpu.min_gpu_bytes() == 128 << 10
+    assert modgpu.min_gpu_bytes() == 16 << 20  # the measured crossover against one host thread (profiles/r03_small_call_crossover.txt)
     before = modgpu.path_stats()
     body = oracle.splitmix_bytes(4092, 0x4D6F64756C617465)
     got = modgpu.cycle_auto_host(body.copy(), modgpu.KEY_PS4)
@@ -184,13 +184,13 @@ def test_auto_entry_point_uses_host_loop_without_gpu(modgpu, oracle):
     assert after["scalar_calls"] == before["scalar_calls"] + 1 and after["auto_small"] == before["auto_small"] + 1
     assert after["auto_fallbacks"] == before["auto_fallbacks"]
     assert after["scalar_bytes"] == before["scalar_bytes"] + 4092 and after["gpu_calls"] == before["gpu_calls"]
-    big = oracle.splitmix_bytes(300_001, 5)
+    big = oracle.splitmix_bytes((16 << 20) + 1, 5)
     assert np.array_equal(modgpu.cycle_auto_host(big.copy(), modgpu.KEY_PS3), oracle.cycle(big.copy(), oracle.KEY_PS3))
     last = modgpu.path_stats()
     assert last["auto_fallbacks"] == after["auto_fallbacks"] + 1 and last["auto_small"] == after["auto_small"]
 
 
-@pytest.mark.parametrize("setting,want", [("0", 0), ("4096", 4096), ("0x100000", 1 << 20), ("junk", 128 << 10), ("", 128 << 10)])
+@pytest.mark.parametrize("setting,want", [("0", 0), ("4096", 4096), ("0x100000", 1 << 20), ("junk", 16 << 20), ("", 16 << 20)])
 def test_min_gpu_bytes_knob_is_latched_at_load(setting, want):
     """MODGPU_MIN_GPU_BYTES (SURVEY 5 'min-size-for-GPU knob'): read once; n < value -> host loop in modgpu_cycle_auto_host
     only.  On this GPU-less machine the route shows in the counters: below the threshold `auto_small`, at or above it

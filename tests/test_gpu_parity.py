@@ -352,7 +352,7 @@ def test_auto_entry_point_when_a_gpu_call_fails(gpu, strict):
     """modgpu_cycle_auto_host's second branch ("else if (mod_cycle_host(...) != 0) cpu_loop()"): a GPU is
     visible but the attempt fails at set-up (injected).  Without MODGPU_REQUIRE_GPU the library's host loop finishes
     the call bit-exact and is counted; with it the error comes back and the buffer is untouched."""
-    e = dict(os.environ, MODGPU_REQUIRE_GPU=strict)
+    e = dict(os.environ, MODGPU_REQUIRE_GPU=strict, MODGPU_MIN_GPU_BYTES="65536")  # the 3 MB buffers below are for the GPU
     r = subprocess.run([sys.executable, "-c", _FALLBACK_CHILD % ROOT], capture_output=True, text=True, env=e, timeout=600)
     assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 

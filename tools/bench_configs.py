@@ -88,7 +88,17 @@ def main():
     for _ in range(200):
         M.hdr_decrypt_host(hdr)
         M.hdr_encrypt_host(hdr, True)
-    res["config1_4k_hdr_roundtrip_us"] = round((time.perf_counter() - t0) / 200 * 1e6, 1)
+    res["config1_4k_hdr_roundtrip_us"] = round((time.perf_counter() - t0) / 200 * 1e6, 1)  # the kernel, whatever the size (modgpu_hdr_*_host)
+    # what the reference's call sites bind to: CEncryptionCycler::Cycle -> modgpu_cycle_auto_host (size dispatch: the host loop here)
+    before = M.path_stats()
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        H.cycle_via_class(hdr[4:], M.KEY_PS4)
+        H.cycle_via_class(hdr[4:], M.KEY_PS4)
+    res["config1_4k_Cycle_roundtrip_us"] = round((time.perf_counter() - t0) / 2000 * 1e6, 2)
+    after = M.path_stats()
+    res["config1_engine"] = {"auto_small_calls": after["auto_small"] - before["auto_small"], "gpu_calls": after["gpu_calls"] - before["gpu_calls"],
+                             "min_gpu_bytes": M.min_gpu_bytes(), "host_loop_isa": M.host_loop_isa()}
 
     # ---- config 4: 100k synthetic entries -> multi-part .ark + encrypted header, 1 GPU
     tm = T()

@@ -5,6 +5,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Imodulate_amd/csrc tools/tune_cycle.hip -o tools/tune_cycle
 // Run:   tools/tune_cycle [bytes=4294967296] [rounds=5]
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -139,8 +140,89 @@ static int trace_main(uint64_t n, uint32_t grid_cap, bool queue)
     return 0;
 }
 
+// `tune_cycle dvfs [bytes] [launches]`: how launch shapes ride through the clock transient that follows load onset
+// (profiles/r03_first_pass.txt).  For each shape: 300 ms idle, then `launches` launches, each timed by its own pair
+// of events, with a one-wave probe on a second stream sampling the shader clock (s_memtime ticks per 10 us of
+// s_memrealtime).  Answers: is the dip's cost VALU-bound (copy-only rides through it, more workgroups help) or a
+// property of the memory pipeline's clock?
+__global__ void clock_probe(uint64_t *out, int samples, uint64_t period)
+{
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < samples; ++i) {
+        const uint64_t t0 = wall_clock64(), c0 = clock64();
+        uint64_t t1;
+        do {
+            __builtin_amdgcn_s_sleep(8);
+            t1 = wall_clock64();
+        } while (t1 - t0 < period);
+        out[2 * i] = t1;
+        out[2 * i + 1] = ((clock64() - c0) * 100) / (t1 - t0);
+    }
+}
+__global__ void stamp_kernel(uint64_t *out) { if (threadIdx.x == 0) *out = wall_clock64(); }
+
+static int dvfs_main(uint64_t n, int launches)
+{
+    uint8_t *buf;
+    CHECK(hipMalloc(&buf, n + (1 << 20)));
+    CHECK(hipMemset(buf, 0x5A, n));
+    hipStream_t st, pst;
+    CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    CHECK(hipStreamCreateWithFlags(&pst, hipStreamNonBlocking));
+    const int samples = 6000;
+    uint64_t *d_probe, *d_stamp;
+    CHECK(hipMalloc(&d_probe, samples * 16));
+    CHECK(hipMalloc(&d_stamp, (launches + 1) * 8));
+    CycleArgs a{};
+    CHECK(hipMalloc(&a.queue, 64));
+    CHECK(hipMemset(a.queue, 0, 64));
+    a.head_ptr = buf; a.body = buf; a.body_words = n / 16; a.tail_ptr = buf + n;
+    a.base_head = a.base_body = a.base_tail = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
+    struct Shape { const char *name; void (*launch)(const CycleArgs &, uint32_t, hipStream_t); uint32_t grid; };
+    const Shape shapes[] = {
+        {"queue 64 KiB, FULL, grid 200 (shipped)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 200},
+        {"queue 64 KiB, FULL, grid 256", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256},
+        {"queue 64 KiB, FULL, grid 224", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 224},
+        {"queue 64 KiB, COPY-ONLY, grid 200", launch_queue<4, 1024, 0, 1, MODE_COPY, 18>, 200},
+        {"queue 64 KiB, COPY-ONLY, grid 256", launch_queue<4, 1024, 0, 1, MODE_COPY, 18>, 256},
+    };
+    printf("bytes=%llu launches=%d: per launch  ms | GB/s (2*bytes/t) | shader MHz (mean of 10 us samples)\n", (unsigned long long)n, launches);
+    for (const Shape &sh : shapes) {
+        a.stride_mul2 = 2u * lcg::powmod(lcg::A, ((uint64_t)sh.grid * 65536) % lcg::PERIOD);
+        CHECK(hipDeviceSynchronize());
+        usleep(300000);
+        CHECK(hipMemsetAsync(d_probe, 0, samples * 16, pst));
+        hipLaunchKernelGGL(clock_probe, dim3(1), dim3(64), 0, pst, d_probe, samples, (uint64_t)1000);
+        usleep(1000);
+        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, st, d_stamp);
+        for (int i = 0; i < launches; ++i) {
+            sh.launch(a, sh.grid, st);
+            hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, st, d_stamp + i + 1);
+        }
+        CHECK(hipStreamSynchronize(st));
+        CHECK(hipStreamSynchronize(pst));
+        std::vector<uint64_t> stamps(launches + 1), probe(samples * 2);
+        CHECK(hipMemcpy(stamps.data(), d_stamp, stamps.size() * 8, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(probe.data(), d_probe, probe.size() * 8, hipMemcpyDeviceToHost));
+        printf("-- %s\n", sh.name);
+        double total = 0;
+        for (int i = 0; i < launches; ++i) {
+            uint64_t sum = 0, cnt = 0;
+            for (int k = 0; k < samples; ++k)
+                if (probe[2 * k] > stamps[i] && probe[2 * k] <= stamps[i + 1]) { sum += probe[2 * k + 1]; ++cnt; }
+            const double ms = (stamps[i + 1] - stamps[i]) / 1e5;
+            total += ms;
+            printf("   %2d  %.4f  %7.1f  %5llu\n", i + 1, ms, 2.0 * n / ms / 1e6, (unsigned long long)(cnt ? sum / cnt : 0));
+        }
+        printf("   all %d launches: %.4f ms = %.1f GB/s\n", launches, total, 2.0 * n * launches / total / 1e6);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && std::string(argv[1]) == "dvfs")
+        return dvfs_main(argc > 2 ? strtoull(argv[2], nullptr, 0) : (1ull << 32), argc > 3 ? atoi(argv[3]) : 16);
     if (argc > 1 && std::string(argv[1]) == "trace")
         return trace_main(argc > 2 ? strtoull(argv[2], nullptr, 0) : (1ull << 32), argc > 3 ? (uint32_t)atoi(argv[3]) : 256u, argc > 4 && atoi(argv[4]) != 0);
     uint64_t n = argc > 1 ? strtoull(argv[1], nullptr, 0) : (1ull << 32);
