@@ -11,8 +11,9 @@
 //   keystream byte                   ks  = low8(S_j) ^ 0xFF
 //
 // Integer only: this is HBM-bound byte work, no MFMA; LDS holds nothing but an 8-byte ticket mailbox.  One byte costs
-// two v_mad_u64_u32 (the product, then the Mersenne fold 2^31 == 1 mod m as a second multiply-add), a shift and
-// one SDWA add that canonicalises and packs it; "^0xFF" and the data XOR are one v_xnor per dword.
+// two v_mad_u64_u32 (the product, then the Mersenne fold 2^31 == 1 mod m as a second multiply-add, whose carry-out IS
+// the canonicalising +1) and one SDWA add-with-carry that packs it: 20 issue cycles; "^0xFF" and the data XOR are one
+// v_xnor per dword.  (ALG 2 in cycle_kernel_impl.h; ALG 1, one instruction more per byte, stays for A/B in tools/.)
 //
 // Three launch shapes (cycle_kernel.h):
 //   queue   what the roofline is measured on (buffers > 256 MiB): persistent 1024-thread workgroups, 25 per 32 CUs,
@@ -70,14 +71,14 @@ template <int U, int BLOCK, int ALG, int SAUX> struct QueueShape {
     }
 };
 // one word per thread, 256 threads, no pipeline: launch-latency-bound sizes
-using Small = Shape<1, 256, 1, 0, AUX_SC1, 0>;
+using Small = Shape<1, 256, 1, 0, AUX_SC1, 0>; // (latency-bound sizes: the 4-instruction sequence, whose register footprint keeps 8 waves per SIMD)
 // U=8 words x 1024 threads, SDWA keystream, pipelined + loads-first, sc1 stores, workgroup-synchronous bursts
-using Large = Shape<8, 1024, 1, 2, AUX_SC1, 3>;
+using Large = Shape<8, 1024, 2, 2, AUX_SC1, 3>;
 // 1024 threads x 4 words = 64 KiB chunks: measured best under the queue (profiles/r02_tune_cycle_queue_shapes.txt,
 // every row validated): 128 KiB chunks balance coarser, 32 KiB and below saturate the ticket counter (~80 tickets/us
 // chip-wide), 512-thread workgroups and a second chunk of loads in flight lose 1 %; stores sc1+nt gain 0.5-1.8 %
 // over sc1 alone at every size
-using Queue = QueueShape<4, 1024, 1, AUX_SC1 | AUX_NT>;
+using Queue = QueueShape<4, 1024, 2, AUX_SC1 | AUX_NT>;
 } // namespace
 
 uint32_t modgpu_variant_chunk_bytes(int variant)

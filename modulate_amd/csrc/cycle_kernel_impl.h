@@ -11,6 +11,9 @@ namespace {
 
 using u32x4 = uint32_t __attribute__((ext_vector_type(4))); // one dwordx4 lane-word
 
+// ks_word_carry's assembly block works in v[120:127] and s[94:95]: the kernels' own allocation stays below them
+#define MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES __attribute__((amdgpu_num_vgpr(120), amdgpu_num_sgpr(94)))
+
 // Jump tables, baked into the code object (see lcg.h).  kTile* are read with wave-uniform
 // indices; kLanePow once per thread at start-up.
 __constant__ lcg::Table<256> c_lane_pow = lcg::kLanePow;
@@ -48,6 +51,7 @@ __device__ __forceinline__ uint32_t mulmod_canon(uint32_t x, uint32_t y)
 // ---- keystream bytes of one dword --------------------------------------------------------
 // ALG 0: plain C; the compiler packs the four low bytes with shifts / v_perm.
 // ALG 1: canonicalise and pack in one SDWA add per byte: byte J of `w` := low8(X + (X >> 31)).
+// ALG 2: as 1, with the "+ (X >> 31)" taken from the fold's carry-out (ks_word_carry, one block per word): no shift.
 template <int SEL> __device__ __forceinline__ void put_byte(uint32_t &w, uint32_t X)
 {
     uint32_t c = X >> 31; // the only possible excess over the canonical residue is m: +1 mod 256
@@ -65,6 +69,82 @@ template <int J> __device__ __forceinline__ uint32_t state_x(uint32_t s)
 {
     return mul_fold(s, 2u * lcg::kBytePow.v[J]); // non-canonical state of byte J of the word
 }
+
+// ALG 2: the canonicalising "+1 if X >= 2^31" comes out of the fold itself, as a carry.
+// The product is biased by 2^63 (p2' = s * 2y + 2^63: hi' = hi + 2^31, no overflow since hi < 2^31); the fold
+//     q = p2'.lo * m + p2'  =  (hi + lo31 + 2^31) * 2^32  =  (X + 2^31) * 2^32
+// then overflows 64 bits exactly when X >= 2^31, and v_mad_u64_u32 delivers that overflow per lane in its scalar
+// carry-out (VCC).  q.hi = X ^ 2^31: the low byte is X's.  One v_addc_co_u32_sdwa adds the carry and packs the byte:
+// three instructions per byte (mad, mad, addc) instead of four (mad, mad, shift, add) -- 20 issue cycles instead of 24.
+// It matters because the kernel is VALU-bound whenever the shader clock sits below ~1.9 GHz, which is where the chip's
+// power management puts it for the first ~10 ms after load onset (profiles/r03_first_pass.txt, r03_tune_dvfs.txt).
+//
+// None of the second half can be said in C++ (no way to ask for the mad's carry-out, none for an SDWA add-with-carry;
+// and with a visible bias the compiler ORs it into the high dword with a separate instruction).  clang's inline assembly
+// can neither bind an operand to VCC ("{vcc}" is rejected) nor name half of a 64-bit operand, and both are needed (the
+// fold multiplies by the product's LOW dword, the addc consumes the fold's HIGH dword, the carry travels in VCC).  So: one
+// hand-scheduled block per 16-byte word with FIXED temporaries -- v[120:125] (three product slots, rotating), v[126:127]
+// (the fold), s[94:95] (the product mad's unused carry-out, kept away from VCC).  The kernels that use it carry
+// amdgpu_num_vgpr(120) / amdgpu_num_sgpr(94), so the register allocator cannot reach these (as plain clobbers -- and even
+// as early-clobber physical outputs -- it handed them to inputs of the block; the parity tests caught it); they need
+// about 70 VGPRs, and a 1024-thread workgroup may use 128 per lane.  tests/test_capi_cpu.py checks the ISA for both.
+// (Cut into per-byte statements with compiler-allocated temporaries, the carry has to detour through an SGPR pair and an
+//  s_mov into VCC; that form is correct too but measured slower than ALG 1 in the VALU-bound regime.)  Constraints honoured
+// by the schedule:
+//   * gfx9 VOP3 reads one scalar operand per instruction: the multiplier is the scalar, bias pair and zero live in VGPRs;
+//   * gfx940+: a VALU write of VCC needs 2 wait states before a VALU reads it as carry-in (the compiler inserts s_nop 1
+//     there): the product of the byte after next, plus one s_nop 0, sit between each fold and its addc.
+// w[0] comes in holding the lane state s (byte 0 of the word is the state itself), w[1..3] are written whole.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm" // "clobber list contains reserved registers: s94, s95" -- reserved by us, for this
+__device__ __forceinline__ void ks_word_carry(uint32_t s, uint32_t (&w)[4])
+{
+    uint32_t zero = 0;
+    uint64_t bias = 0x8000000000000000ull;
+    asm("" : "+v"(zero), "+v"(bias)); // three VGPRs of constants
+    const uint32_t m = lcg::M;
+    uint32_t w0 = s, w1, w2, w3;
+#define M1(P, Y) "v_mad_u64_u32 v[" P "], s[94:95], %[s], %[" Y "], %[bias]\n\t"
+#define M2(PLO, P) "v_mad_u64_u32 v[126:127], vcc, v" PLO ", %[m], v[" P "]\n\t"
+#define NOP0 "s_nop 0\n\t"
+#define NOP1 "s_nop 1\n\t"
+#define AC(W, SEL, UNUSED) "v_addc_co_u32_sdwa %[" W "], vcc, v127, %[zero], vcc dst_sel:BYTE_" SEL " dst_unused:" UNUSED " src0_sel:DWORD src1_sel:DWORD\n\t"
+    asm(
+        M1("120:121", "y1")
+        M1("122:123", "y2")
+        M2("120", "120:121") M1("124:125", "y3") NOP0 AC("w0", "1", "UNUSED_PRESERVE")
+        M2("122", "122:123") M1("120:121", "y4") NOP0 AC("w0", "2", "UNUSED_PRESERVE")
+        M2("124", "124:125") M1("122:123", "y5") NOP0 AC("w0", "3", "UNUSED_PRESERVE")
+        M2("120", "120:121") M1("124:125", "y6") NOP0 AC("w1", "0", "UNUSED_PAD")
+        M2("122", "122:123") M1("120:121", "y7") NOP0 AC("w1", "1", "UNUSED_PRESERVE")
+        M2("124", "124:125") M1("122:123", "y8") NOP0 AC("w1", "2", "UNUSED_PRESERVE")
+        M2("120", "120:121") M1("124:125", "y9") NOP0 AC("w1", "3", "UNUSED_PRESERVE")
+        M2("122", "122:123") M1("120:121", "y10") NOP0 AC("w2", "0", "UNUSED_PAD")
+        M2("124", "124:125") M1("122:123", "y11") NOP0 AC("w2", "1", "UNUSED_PRESERVE")
+        M2("120", "120:121") M1("124:125", "y12") NOP0 AC("w2", "2", "UNUSED_PRESERVE")
+        M2("122", "122:123") M1("120:121", "y13") NOP0 AC("w2", "3", "UNUSED_PRESERVE")
+        M2("124", "124:125") M1("122:123", "y14") NOP0 AC("w3", "0", "UNUSED_PAD")
+        M2("120", "120:121") M1("124:125", "y15") NOP0 AC("w3", "1", "UNUSED_PRESERVE")
+        M2("122", "122:123") NOP1 AC("w3", "2", "UNUSED_PRESERVE")
+        M2("124", "124:125") NOP1 AC("w3", "3", "UNUSED_PRESERVE")
+        : [w0] "+&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3)
+        : [s] "v"(s), [bias] "v"(bias), [zero] "v"(zero), [m] "s"(m),
+          [y1] "s"(2u * lcg::kBytePow.v[1]), [y2] "s"(2u * lcg::kBytePow.v[2]), [y3] "s"(2u * lcg::kBytePow.v[3]), [y4] "s"(2u * lcg::kBytePow.v[4]),
+          [y5] "s"(2u * lcg::kBytePow.v[5]), [y6] "s"(2u * lcg::kBytePow.v[6]), [y7] "s"(2u * lcg::kBytePow.v[7]), [y8] "s"(2u * lcg::kBytePow.v[8]),
+          [y9] "s"(2u * lcg::kBytePow.v[9]), [y10] "s"(2u * lcg::kBytePow.v[10]), [y11] "s"(2u * lcg::kBytePow.v[11]), [y12] "s"(2u * lcg::kBytePow.v[12]),
+          [y13] "s"(2u * lcg::kBytePow.v[13]), [y14] "s"(2u * lcg::kBytePow.v[14]), [y15] "s"(2u * lcg::kBytePow.v[15])
+        : "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s94", "s95", "vcc");
+#undef M1
+#undef M2
+#undef NOP0
+#undef NOP1
+#undef AC
+    w[0] = w0;
+    w[1] = w1;
+    w[2] = w2;
+    w[3] = w3;
+}
+#pragma clang diagnostic pop
 
 // Low bytes of the canonical states of bytes J0..J0+3 of the word whose first byte has
 // canonical state s, packed little-endian.
@@ -90,6 +170,15 @@ template <int J0, int ALG> __device__ __forceinline__ uint32_t ks_state_dword(ui
 // keystream = ~state_bytes  =>  data ^ ks = ~(data ^ state_bytes)  (one v_xnor per dword).
 template <int ALG> __device__ __forceinline__ u32x4 cycle_word(u32x4 d, uint32_t s)
 {
+    if constexpr (ALG == 2) {
+        uint32_t w[4];
+        ks_word_carry(s, w);
+        d.x = ~(d.x ^ w[0]);
+        d.y = ~(d.y ^ w[1]);
+        d.z = ~(d.z ^ w[2]);
+        d.w = ~(d.w ^ w[3]);
+        return d;
+    }
     d.x = ~(d.x ^ ks_state_dword<0, ALG>(s));
     d.y = ~(d.y ^ ks_state_dword<4, ALG>(s));
     d.z = ~(d.z ^ ks_state_dword<8, ALG>(s));
@@ -148,7 +237,7 @@ constexpr int AUX_SC1 = 16; // system-coherent / write-through -- best for the s
 // LDSW  = 1 (tools/tune_cycle only; the north_star's "LDS as a write-combine stage", measured, not shipped):
 //         each trip's finished words go registers -> LDS -> registers before the store burst
 template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = AUX_SC1, int SYNC = 0, int TRACE = 0, int LDSW = 0>
-__global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
+__global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void modgpu_cycle_kernel(CycleArgs a)
 {
     static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
     constexpr uint32_t CHUNK = (uint32_t)U * BLOCK * lcg::WORD; // bytes per workgroup trip
@@ -333,7 +422,7 @@ __global__ __launch_bounds__(BLOCK) void modgpu_cycle_kernel(CycleArgs a)
 //         hand-off races; answers what a barrier-free workgroup would gain.  B2 = 2 (tools/tune_cycle): the
 //         barrier sits behind the store burst instead of in front of it (waves store as they finish)
 template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int LAUX = AUX_NT, int B1 = 1, int B2 = 1>
-__global__ __launch_bounds__(BLOCK) void modgpu_cycle_queue_kernel(CycleArgs a)
+__global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void modgpu_cycle_queue_kernel(CycleArgs a)
 {
     static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
     static_assert(DEPTH >= 1 && DEPTH <= 3, "1..3 chunks of loads in flight");

@@ -153,14 +153,29 @@ void CArkDataBuffer::Release()
     muSize = 0;
 }
 
-bool CArkDataBuffer::Allocate( uint64_t luSize )
+bool CArkDataBuffer::Allocate( uint64_t luSize, const std::vector< uint64_t >& laPartSizes, int liNumDevices )
 {
     Release();
     void* lp = nullptr;
-    if( modgpu_host_alloc( &lp, luSize ) != MODGPU_OK ) return false;
+    uint64_t luSum = 0;
+    for( uint64_t luPart : laPartSizes ) luSum += luPart;
+    // With the part plan known, the buffer is still ONE contiguous allocation (the reference's layout, CArk.cpp:738, 780),
+    // but each part's pages sit on the NUMA node of the GPU the part cipher will send it to (part i -> GPU i mod N), and
+    // the pages are first-touched in parallel before they are locked -- half the time of one hipHostMalloc of the whole.
+    const int liStatus = ( !laPartSizes.empty() && luSum == luSize )
+                             ? modgpu_host_alloc_parts( &lp, laPartSizes.data(), (int)laPartSizes.size(), liNumDevices )
+                             : modgpu_host_alloc( &lp, luSize );
+    if( liStatus != MODGPU_OK ) return false;
     mpData = static_cast< char* >( lp );
     muSize = luSize;
     return true;
+}
+
+std::vector< uint64_t > CArk::PartSizes() const
+{
+    std::vector< uint64_t > laSizes;
+    for( const sArkDefinition& a : maArks ) laSizes.push_back( a.muSize );
+    return laSizes;
 }
 
 CArk::CArk() = default;
@@ -304,7 +319,7 @@ eError CArk::LoadArkData() // CArk.cpp:723-758
         if( !fs::is_regular_file( lPaths.back(), ec ) ) { eError leError = eError_FailedToOpenFile; SHOW_ERROR_AND_RETURN; }
         if( fs::file_size( lPaths.back(), ec ) < a.muSize ) { eError leError = eError_InvalidData; SHOW_ERROR_AND_RETURN; } // the reference does not check (CArk.cpp:751)
     }
-    if( !maArkData.Allocate( luTotalArkSize ) ) { eError leError = eError_NoData; SHOW_ERROR_AND_RETURN; } // CArk.cpp:738
+    if( !maArkData.Allocate( luTotalArkSize, PartSizes(), miPartDevices ) ) { eError leError = eError_NoData; SHOW_ERROR_AND_RETURN; } // CArk.cpp:738
     if( !mbPartCipher ) // the reference's behaviour: parts are stored raw
     {
         for( size_t ii = 0; ii < maArks.size(); ++ii )
@@ -540,7 +555,7 @@ eError CArk::BuildArk( const char* lpInputDirectory, std::vector< SSongConfig > 
     SHOW_ERROR_AND_RETURN;
     uint64_t luTotalArkSize = 0;
     for( const sFileDefinition& f : maFiles ) luTotalArkSize += (uint64_t)f.miSize;
-    if( !maArkData.Allocate( luTotalArkSize ) ) { leError = eError_NoData; SHOW_ERROR_AND_RETURN; } // CArk.cpp:780
+    if( !maArkData.Allocate( luTotalArkSize, PartSizes(), miPartDevices ) ) { leError = eError_NoData; SHOW_ERROR_AND_RETURN; } // CArk.cpp:780
     const std::string lInput = WithSlash( lpInputDirectory );
     leError = ParallelOverEntries( 0, (int)maFiles.size(), [ & ]( int ii ) -> eError {
         const sFileDefinition& f = maFiles[ ii ];
@@ -563,7 +578,7 @@ eError CArk::BuildArkFromMemory( const char* lpData, uint64_t luDataSize )
     if( luTotal != luDataSize || ( luDataSize && !lpData ) ) return eError_InvalidParameter;
     eError leError = SplitIntoArks();
     ERROR_RETURN;
-    if( !maArkData.Allocate( luDataSize ) ) return eError_NoData;
+    if( !maArkData.Allocate( luDataSize, PartSizes(), miPartDevices ) ) return eError_NoData;
     if( luDataSize ) std::memcpy( maArkData.data(), lpData, (size_t)luDataSize );
     return eError_NoError;
 }

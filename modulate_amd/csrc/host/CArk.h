@@ -30,7 +30,7 @@ struct SSongConfig
 };
 
 // The concatenated part buffer (the reference's `char* mpArkData`, CArk.h:88, `new char[total]` at
-// CArk.cpp:738, 780).  Allocated through modgpu_host_alloc: page-locked and device-visible when a GPU
+// CArk.cpp:738, 780).  Allocated through modgpu_host_alloc / modgpu_host_alloc_parts: page-locked and device-visible when a GPU
 // is present, so the part cipher DMAs straight from / to these pages (no staging copy); ordinary
 // memory otherwise.  Contents are uninitialised after Allocate, as after the reference's new[].
 class CArkDataBuffer
@@ -40,7 +40,9 @@ public:
     ~CArkDataBuffer();
     CArkDataBuffer( const CArkDataBuffer& ) = delete;
     CArkDataBuffer& operator=( const CArkDataBuffer& ) = delete;
-    bool Allocate( uint64_t luSize ); // false: out of memory
+    // false: out of memory.  laPartSizes (optional; must add up to luSize): the parts that will be laid end to end in the
+    // buffer -- their pages are then placed next to the GPU each part goes to (modgpu_host_alloc_parts).
+    bool Allocate( uint64_t luSize, const std::vector< uint64_t >& laPartSizes = {}, int liNumDevices = 0 );
     void Release();
     char* data() { return mpData; }
     const char* data() const { return mpData; }
@@ -139,6 +141,7 @@ private:
     bool mbPartCipher = false;
     int miPartDevices = 0;
     int miLoadedKey = 0;                            // key selected by the loaded header's magic
+    std::vector< uint64_t > PartSizes() const; // maArks[].muSize
     std::string mHeaderDirectory; // where Load found the header: part paths resolve against it
     std::string mWorkingDirectory; // SetWorkingDirectory
     bool mbLoaded = false;

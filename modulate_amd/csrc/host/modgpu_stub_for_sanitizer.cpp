@@ -23,6 +23,12 @@ int modgpu_device_count( void ) { return 0; }
 int modgpu_cycle_file_to_host( const char*, uint64_t, uint8_t*, uint64_t, int32_t, uint64_t, int ) { return MODGPU_ERR_NO_DEVICE; }
 int modgpu_cycle_host_to_file( const uint8_t*, uint64_t, const char*, int32_t, uint64_t, int ) { return MODGPU_ERR_NO_DEVICE; }
 int modgpu_host_alloc( void** p, uint64_t n ) { *p = std::malloc( n ? n : 1 ); return *p ? MODGPU_OK : MODGPU_ERR_INVALID; }
+int modgpu_host_alloc_parts( void** p, const uint64_t* sizes, int n, int )
+{
+    uint64_t total = 0;
+    for( int i = 0; i < n; ++i ) total += sizes[ i ];
+    return modgpu_host_alloc( p, total );
+}
 int modgpu_host_free( void* p ) { std::free( p ); return MODGPU_OK; }
 int modgpu_host_is_pinned( const void*, uint64_t ) { return 0; }
 }

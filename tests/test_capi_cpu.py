@@ -342,6 +342,26 @@ def test_queue_kernel_codegen_keeps_the_ticket_atomic_asynchronous():
     hot_stores = [ln for ln in stores if ln.rstrip().endswith("nt sc1")]
     assert len(hot_stores) >= 8  # 4 words x 2 unrolled trips (+ the cold peel loop)
     assert shutil.which("make")
+    # ---- the keystream sequence (ALG 2, ks_word_carry): per byte two v_mad_u64_u32 and ONE v_addc_co_u32_sdwa that takes the
+    # canonicalising +1 from the fold's carry-out -- no shift, no separate add
+    assert body.count("v_addc_co_u32_sdwa") == 9 * 15  # 4 words x 2 unrolled trips + the peeled first chunk, 15 bytes each
+    assert "v_add_u32_sdwa" not in body
+    # ... whose hand-scheduled block works in FIXED temporaries, v[120:127] and s[94:95], kept out of the register allocator's
+    # reach by amdgpu_num_vgpr(120) / amdgpu_num_sgpr(94) on the kernels.  Nothing outside the blocks may touch them, and no
+    # operand the compiler chose for a block may lie inside them (as plain clobbers it did hand them to inputs: wrong bytes).
+    fixed = re.compile(r"\bv12[0-7]\b|v\[\d+:12[0-7]\]|\bs9[45]\b|s\[\d+:9[45]\]")
+    for name in ("_Z25modgpu_cycle_queue_kernel", "_Z19modgpu_cycle_kernelILi8ELi1024ELi2"):
+        st = asm.index(name)
+        fn = asm[asm.index(":", st):asm.index("s_endpgm", st)]
+        blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", fn, flags=re.S)
+        carry = [b for b in blocks if "s[94:95]" in b]
+        assert carry, name
+        outside = re.sub(r";;#ASMSTART\n.*?;;#ASMEND", "", fn, flags=re.S)
+        assert not [ln for ln in outside.splitlines() if fixed.search(ln) and not ln.strip().startswith(";")], name
+        for b in carry:
+            for ln in b.splitlines():
+                chosen = re.sub(r"v\[12[0246]:12[1357]\]|s\[94:95\]|\bv12[0246]\b|\bv127\b", "", ln)  # what is left was allocated by the compiler
+                assert not fixed.search(chosen), ln
 
 
 @pytest.mark.parametrize("env,want", [

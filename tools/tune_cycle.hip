@@ -42,9 +42,10 @@ template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = 16, int SYNC
     hipLaunchKernelGGL((modgpu_cycle_kernel<U, BLOCK, ALG, PIPE, MODE, SAUX, SYNC, TRACE, LDSW>), dim3(grid), dim3(BLOCK), 0, st, a);
 }
 
-template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int SAUX = 16, int LAUX = 2, int B1 = 1, int B2 = 1> void launch_queue(const CycleArgs &a, uint32_t grid, hipStream_t st)
+// ALG: 2 = the shipped keystream sequence (canonicalising carry out of the fold, 3 instructions per byte), 1 = round 2's (4 per byte)
+template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int SAUX = 16, int LAUX = 2, int B1 = 1, int B2 = 1, int ALG = 2> void launch_queue(const CycleArgs &a, uint32_t grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, 1, SAUX, TRACE, DEPTH, MODE, LAUX, B1, B2>), dim3(grid), dim3(BLOCK), 0, st, a);
+    hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, ALG, SAUX, TRACE, DEPTH, MODE, LAUX, B1, B2>), dim3(grid), dim3(BLOCK), 0, st, a);
 }
 
 // `tune_cycle trace <bytes> [grid]`: where a launch's time goes.  Runs the shipped streaming shape with
@@ -180,11 +181,15 @@ static int dvfs_main(uint64_t n, int launches)
     a.base_head = a.base_body = a.base_tail = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
     struct Shape { const char *name; void (*launch)(const CycleArgs &, uint32_t, hipStream_t); uint32_t grid; };
     const Shape shapes[] = {
-        {"queue 64 KiB, FULL, grid 200 (shipped)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 200},
-        {"queue 64 KiB, FULL, grid 256", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256},
-        {"queue 64 KiB, FULL, grid 224", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 224},
+        {"queue 64 KiB, FULL alg 2 (carry from the fold), grid 200", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 200},
+        {"queue 64 KiB, FULL alg 2, grid 208", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 208},
+        {"queue 64 KiB, FULL alg 2, grid 216", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 216},
+        {"queue 64 KiB, FULL alg 2, grid 224", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 224},
+        {"queue 64 KiB, FULL alg 2, grid 256", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256},
+        {"queue 64 KiB, FULL alg 1 (round 2: shift + add), grid 200", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 1>, 200},
+        {"queue 64 KiB, FULL alg 1, grid 224", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 1>, 224},
+        {"queue 64 KiB, FULL alg 1, grid 256", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 1>, 256},
         {"queue 64 KiB, COPY-ONLY, grid 200", launch_queue<4, 1024, 0, 1, MODE_COPY, 18>, 200},
-        {"queue 64 KiB, COPY-ONLY, grid 256", launch_queue<4, 1024, 0, 1, MODE_COPY, 18>, 256},
     };
     printf("bytes=%llu launches=%d: per launch  ms | GB/s (2*bytes/t) | shader MHz (mean of 10 us samples)\n", (unsigned long long)n, launches);
     for (const Shape &sh : shapes) {
@@ -215,6 +220,16 @@ static int dvfs_main(uint64_t n, int launches)
             printf("   %2d  %.4f  %7.1f  %5llu\n", i + 1, ms, 2.0 * n / ms / 1e6, (unsigned long long)(cnt ? sum / cnt : 0));
         }
         printf("   all %d launches: %.4f ms = %.1f GB/s\n", launches, total, 2.0 * n * launches / total / 1e6);
+        // an even number of launches must give the fill pattern back (a shape that drops or repeats chunks looks fast)
+        unsigned long long *d_bad, bad = 0;
+        CHECK(hipMalloc(&d_bad, 8));
+        CHECK(hipMemset(d_bad, 0, 8));
+        if (launches % 2) sh.launch(a, sh.grid, st);
+        hipLaunchKernelGGL(count_mismatches, dim3(2048), dim3(256), 0, st, (const uint32_t *)buf, n / 4, 0x5A5A5A5Au, d_bad);
+        CHECK(hipStreamSynchronize(st));
+        CHECK(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
+        CHECK(hipFree(d_bad));
+        if (bad) printf("   ** INVALID: %llu words differ after an even number of passes **\n", bad);
     }
     return 0;
 }
@@ -310,6 +325,10 @@ int main(int argc, char **argv)
     ADDQX(8, 1024, 1, 18, 2, 1, 192);
     ADDQX(8, 1024, 1, 18, 2, 1, 160);
     ADDQX(8, 512, 1, 18, 2, 1, 192);
+    vs.push_back({0, "queue   U= 4 B=1024 st=18 ALG 2 (shipped: carry from the fold)  64 KiB grid= 200", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 65536, autogrid(65536, 200), {}});
+    vs.push_back({0, "queue   U= 4 B=1024 st=18 ALG 1 (round 2: shift + add)          64 KiB grid= 200", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 1>, 65536, autogrid(65536, 200), {}});
+    vs.push_back({0, "queue   U= 4 B=1024 st=18 ALG 2                                 64 KiB grid= 224", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 65536, autogrid(65536, 224), {}});
+    vs.push_back({0, "queue   U= 4 B=1024 st=18 ALG 2                                 64 KiB grid= 256", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 65536, autogrid(65536, 256), {}});
     vs.push_back({0, "queue   U= 4 B=1024 st=18 b1=0, barrier BEHIND the store burst 64 KiB grid= 256", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 0, 2>, 65536, autogrid(65536, 256), {}});
     vs.push_back({0, "queue   U= 4 B=1024 st=18 b1=1, barrier BEHIND the store burst 64 KiB grid= 256", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 2>, 65536, autogrid(65536, 256), {}});
     vs.push_back({0, "queue   U= 8 B= 512 st=18 b1=0, barrier BEHIND the store burst 64 KiB grid= 256", launch_queue<8, 512, 0, 1, MODE_FULL, 18, 2, 0, 2>, 65536, autogrid(65536, 256), {}});
