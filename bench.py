@@ -267,7 +267,7 @@ def main():
                                  f"{stats['scalar_calls']} host-loop calls on rank 0"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": launch["kernel"], "grid": launch["grid"], "block": launch["block"],
+                         "kernel": launch["kernel"], "grid": launch["grid"], "main_workgroups": launch["main_groups"], "block": launch["block"],
                          "chunk_bytes": launch["chunk_bytes"], "kernel_source_hash": M.kernel_source_hash(),
                          "ms_per_launch": round(ms_per_launch, 4), "algorithmic_bytes_per_launch": 2 * n,
                          # which launches of this kernel (in launch order, from 0) the HIP events of the timed region bracket:

@@ -33,10 +33,12 @@ typedef struct modgpu_launch_info {
     const char *kernel;   /* the instantiation's name as rocprofv3 prints it, e.g.
                              "modgpu_cycle_queue_kernel<4, 1024, 1, 18, 0, 1, 0, 2, 1, 1>"; static storage */
     int variant;          /* 0 = small shape, 1 = streaming shape (static chunk map), 2 = streaming shape fed by the work queue */
-    uint32_t grid;        /* workgroups                                                           */
+    uint32_t grid;        /* workgroups launched                                                  */
     uint32_t block;       /* threads per workgroup                                                */
     uint32_t chunk_bytes; /* bytes one workgroup trip covers                                      */
     uint64_t bytes;       /* n of that launch                                                     */
+    uint32_t main_groups; /* of `grid`: workgroups that stream from the start; the other grid - main_groups are helper
+                             workgroups of the work-queue shape, which join only while the shader clock is low */
 } modgpu_launch_info_t;
 int modgpu_last_launch(modgpu_launch_info_t *out);
 
@@ -72,6 +74,11 @@ int modgpu_testing_hooks(void);
  * 4096).  With one line every second launch in flight finds the ring busy: the collision the gating exists for
  * becomes certain instead of a 1-in-4096 event. */
 void modgpu_debug_set_queue_ring(uint32_t lines);
+
+/* Helper workgroups of the work-queue shape (one per CU the main workgroups leave idle; they join only while the shader clock is
+ * low): 0 = decide by the clock they measure (the shipped behaviour), 1 = always join, 2 = launch none.  Lets the parity tests
+ * run both branches whatever the chip's clock happens to be. */
+void modgpu_debug_set_helpers(int mode);
 
 /* Forces the launch shape of every later launch in this process (-1 = by size, the default) and
  * caps the grid (0 = no cap).  Lets the parity tests run the streaming kernels with 1, 2, odd and

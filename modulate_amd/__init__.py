@@ -13,6 +13,6 @@ from .capi import (  # noqa: F401
     hdr_encrypt_host, cycle_parts_host, cycle_parts_device, cycle_file, cycle_file_to_host, cycle_host_to_file, DeviceBuffer, time_cycle_device, state_at, jump_table,
     KEY_PS3, KEY_PS4, MAGIC_PS3, MAGIC_PS4, as_int32, EXPORTS, TESTING_EXPORTS, cycle_scalar_host, cycle_auto_host,
     path_stats, gpu_required, last_launch, debug_set_launch, debug_set_pinned_mode, debug_set_staged_mode, kernel_source_hash, host_tunables, debug_inject_failures, PinnedBuffer, host_register, host_unregister,
-    DEBUG_EXPORTS, FLAVOURS, testing_flavour, use_testing_flavour, active_flavour, debug_set_queue_ring, queue_stats, testing_hooks, min_gpu_bytes,
+    DEBUG_EXPORTS, FLAVOURS, testing_flavour, use_testing_flavour, active_flavour, debug_set_queue_ring, debug_set_helpers, queue_stats, testing_hooks, min_gpu_bytes,
     host_loop_isa, cycle_scalar_host_isa, device_numa_node, numa_probe,
 )

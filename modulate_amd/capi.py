@@ -72,7 +72,7 @@ class PathStats(ctypes.Structure):
 class LaunchInfo(ctypes.Structure):
     """modgpu_launch_info_t (include/modgpu_testing.h)."""
     _fields_ = [("kernel", ctypes.c_char_p), ("variant", _int), ("grid", ctypes.c_uint32), ("block", ctypes.c_uint32),
-                ("chunk_bytes", ctypes.c_uint32), ("bytes", _u64)]
+                ("chunk_bytes", ctypes.c_uint32), ("bytes", _u64), ("main_groups", ctypes.c_uint32)]
 
 
 # include/modgpu_testing.h, reporting group: in both flavours (measurement, not the drop-in boundary)
@@ -92,6 +92,7 @@ DEBUG_EXPORTS = {
     "modgpu_debug_set_pinned_mode": (None, [_int]),
     "modgpu_debug_set_staged_mode": (None, [_int]),
     "modgpu_debug_set_queue_ring": (None, [ctypes.c_uint32]),
+    "modgpu_debug_set_helpers": (None, [_int]),
     "modgpu_debug_inject_failures": (None, [_int]),
 }
 
@@ -217,7 +218,7 @@ def last_launch():
     info = LaunchInfo()
     _check(lib().modgpu_last_launch(ctypes.byref(info)))
     return {"kernel": info.kernel.decode(), "variant": info.variant, "grid": info.grid, "block": info.block,
-            "chunk_bytes": info.chunk_bytes, "bytes": info.bytes}
+            "chunk_bytes": info.chunk_bytes, "bytes": info.bytes, "main_groups": info.main_groups}
 
 
 SHAPES = {None: -1, "auto": -1, "small": 0, "large": 1, "queue": 2}
@@ -242,6 +243,11 @@ def debug_set_staged_mode(mode=0):
 def debug_inject_failures(count):
     """Test hook: the next `count` host-buffer / file calls fail with MODGPU_ERR_HIP before touching anything."""
     _debug_lib().modgpu_debug_inject_failures(count)
+
+
+def debug_set_helpers(mode=0):
+    """Test hook: helper workgroups of the work-queue shape: 0 by the clock they measure, 1 always join, 2 none."""
+    _debug_lib().modgpu_debug_set_helpers(mode)
 
 
 def debug_set_queue_ring(lines=0):

@@ -21,6 +21,9 @@ struct CycleArgs {
     uint32_t *queue;     // work-queue shape only: {ticket counter, workgroups done}, both 0 at launch and 0 again at exit
     uint32_t *queue_done; // work-queue shape: host-visible word that receives queue_seq once the pair is clean again (the host
     uint32_t queue_seq;   // hands a pair out again only after it has seen that); nullptr: nobody waits for this pair
+    uint32_t main_groups;      // work-queue shape: workgroups [0, main_groups) stream from the start; the rest are HELPERS, which
+    uint32_t helper_below_mhz; // measure the shader clock when they start and join (tickets only) while it is below this many MHz,
+                               // else leave at once.  0 main_groups = every workgroup is a main one.
     uint64_t *trace;     // nullptr in the product.  tools/tune_cycle's TRACE instantiation writes per-workgroup
                          // timestamps here (wall_clock64, 100 MHz): [blk*32+0] start, [+1+k] end of trip k, [+31] XCC id
 };

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
 // every workgroup does the same number of trips, but the CUs are not equally fast: the workgroups of every
 // other XCD take ~9.6 us per trip, the rest ~11 us (profiles/r02_trace_static_schedule.txt), so half the
 // chip idles at the end of every launch while the other half finishes.  Here a workgroup's first three
-// chunks are static (b, b+G, b+2G: no start-up latency) and every later one is a ticket from a global
+// chunks are static (b, b+Gm, b+2Gm among the Gm main workgroups: no start-up latency) and every later one is a ticket from a global
 // counter, fetched a full trip before it is needed, so fast CUs simply take more chunks and all of them
 // finish within one trip of each other.
 //
@@ -433,6 +433,7 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
     const uint32_t tid = threadIdx.x;
     const uint32_t blk = blockIdx.x;
     const uint32_t G = gridDim.x;
+    const uint32_t Gm = a.main_groups != 0 && a.main_groups < G ? a.main_groups : G; // main workgroups; [Gm, G) are helpers (below)
     // Two LDS words, used alternately: a trip's ticket is written before that trip's barrier and read after it, and
     // the same word is written again two trips later -- i.e. behind the NEXT trip's barrier, which no wave can reach
     // before it has done this trip's read.  (With a single word, correctness would lean on the other barrier, the
@@ -533,17 +534,51 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
     auto take_published = [&]() { // every lane, after the trip's barrier (trip already counted: the word is (trip-1)&1)
         uint32_t t;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(q_next_lds + 4u * ((trip - 1u) & 1u)) : "memory");
-        return first + (uint32_t)PREFIX * G + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        return first + (uint32_t)PREFIX * Gm + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     };
 
     // A workgroup's chunk sequence: positions 0 .. PREFIX-1 are static (b, b+G, ...), position j + PREFIX is the
     // ticket fetched in trip j.  cq[] holds positions k .. k+DEPTH at the start of trip k: cq[0] is computed,
     // cq[DEPTH] is loaded now, the ones between are already in flight.
     uint32_t cq[NB];
+    uint32_t last_static; // position PREFIX-1, enters cq after trip 0
+    bool active = true;
+    if (blk < Gm) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) cq[i] = first + blk + (uint32_t)i * G;
-    const uint32_t last_static = first + blk + (uint32_t)NB * G; // position PREFIX-1, enters cq after trip 0
-    if (cq[0] < n_chunks) {
+        for (int i = 0; i < NB; ++i) cq[i] = first + blk + (uint32_t)i * Gm;
+        last_static = first + blk + (uint32_t)NB * Gm;
+    } else {
+        // A HELPER workgroup.  With the chip's clock where it normally is (2.1-2.2 GHz) the 25-per-32-CU main workgroups
+        // saturate HBM and more streams only hurt (-1.8 % at one per CU).  For the first ~10 ms after load onset,
+        // though, power management holds the shader clock at 1.2-1.7 GHz, and there the main workgroups run out of
+        // ARITHMETIC (profiles/r03_first_pass.txt): the idle CUs' SIMDs are then worth more than the tidy memory
+        // pattern (flat 6.85 TB/s with a workgroup on every CU against a dip to 6.2-6.4).  So the idle CUs get a
+        // workgroup each that looks at the clock ONCE, when it starts -- shader-clock ticks (s_memtime) per 2 us of the
+        // constant 100 MHz counter (s_memrealtime) -- and either joins, taking its first PREFIX chunks and all later
+        // ones from the ticket counter, or leaves at once.  (Helpers that stay and keep watching the clock were tried:
+        // correct, but with 56 workgroups standing by the main ones ran 15 % slower at full clock --
+        // profiles/r03_tune_dvfs.txt keeps that row.)
+        if (tid == 0) {
+            const uint64_t t0 = wall_clock64(), c0 = clock64();
+            uint64_t t1;
+            do {
+                __builtin_amdgcn_s_sleep(4);
+                t1 = wall_clock64();
+            } while (t1 - t0 < 200);
+            const uint64_t mhz = ((clock64() - c0) * 100) / (t1 - t0);
+            uint32_t t = 0xFFFFFFFFu;
+            if (mhz < a.helper_below_mhz) t = __hip_atomic_fetch_add(a.queue, (uint32_t)PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q_next[0] = t;
+        }
+        __syncthreads();
+        const uint32_t t = q_next[0];
+        __syncthreads(); // (the loop below writes q_next[0] again, two trips in)
+        active = t != 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) cq[i] = first + (uint32_t)PREFIX * Gm + t + (uint32_t)i;
+        last_static = first + (uint32_t)PREFIX * Gm + t + (uint32_t)NB;
+    }
+    if (active && cq[0] < n_chunks) {
         u32x4 d[NB][U];
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) load(d[i], cq[i]);

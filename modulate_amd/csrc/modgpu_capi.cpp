@@ -344,6 +344,16 @@ void queue_pair_unused(const QueuePair &q)
     --r.issued[q.line];
 }
 
+// Helper workgroups of the work-queue shape join while the shader clock is below this: with the three-instruction keystream
+// the 25-per-32 main workgroups stay HBM-bound down to ~1.7 GHz (profiles/r03_first_pass.txt: 1 711 MHz 6.97 TB/s, 1 645 6.87, 1 579 6.69)
+constexpr uint32_t kHelperBelowMHz = 1750;
+#ifdef MODGPU_TESTING_HOOKS
+std::atomic<int> g_helper_mode{0}; // modgpu_debug_set_helpers: 0 by the clock, 1 always join, 2 no helper workgroups
+int helper_mode() { return g_helper_mode.load(std::memory_order_relaxed); }
+#else
+constexpr int helper_mode() { return 0; }
+#endif
+
 constexpr uint32_t kSmallGridMax = 16384u;   // 4 KiB chunks: grid * 1 tile <= 65536
 // Hand-over between the two shapes, measured warm and cold (profiles/r01_tune_cycle_sizes*.txt):
 // up to 256 MiB the one-shot 4 KiB-chunk grid wins (launch cost ~3 us vs ~9 us, and the buffer fits
@@ -405,11 +415,29 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
     // With chunks handed out by tickets any grid finishes the job, and the memory system does best with fewer
     // streams than CUs: 25 workgroups per 32 CUs (200 on MI355X) -- measured plateau 184..208, +1.6 % at 4 GiB and
     // +2.4 % at 402 MiB over one per CU; 160 and below fall off (profiles/r02_tune_cycle_queue_grid.txt).
-    if (p.variant == CYCLE_QUEUE) cap = std::max<uint64_t>(1, cap * 25 / 32);
-    if (over_pcie) cap = std::min<uint64_t>(cap, kPcieGridMax);
+    // ... at the clock the chip normally runs at.  While power management holds the shader clock low (the first ~10 ms after
+    // load onset) the kernel is bound by its arithmetic instead, and the CUs left idle are worth more than the tidy memory
+    // pattern: they get a HELPER workgroup each, which measures the clock when it starts and joins the ticket queue only
+    // while it is below kHelperBelowMHz (cycle_kernel_impl.h; profiles/r03_first_pass.txt, r03_tune_dvfs.txt).
+    uint64_t helpers = 0;
     const uint32_t grid_cap = forced_grid_cap();
-    if (grid_cap >= 1 && grid_cap < cap) cap = grid_cap;
-    p.grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(chunks, cap));
+    if (p.variant == CYCLE_QUEUE) {
+        const uint64_t cus = cap;
+        cap = std::max<uint64_t>(1, cus * 25 / 32);
+        const bool capped = grid_cap >= 1 && grid_cap < cus; // (testing flavour: a forced grid)
+        if (capped && grid_cap < cap) cap = grid_cap;
+        // (a launch of a few trips is over before a helper has looked at the clock; a forced grid gets helpers only when the
+        //  tests force them to join, in the product's proportion)
+        if (helper_mode() == 1) helpers = capped ? std::max<uint64_t>(1, cap * 7 / 25) : cus - cap;
+        else if (helper_mode() == 0 && !capped && chunks >= 4 * cus) helpers = cus - cap;
+    } else if (grid_cap >= 1 && grid_cap < cap) {
+        cap = grid_cap;
+    }
+    if (over_pcie) cap = std::min<uint64_t>(cap, kPcieGridMax);
+    const uint64_t main_groups = std::max<uint64_t>(1, std::min<uint64_t>(chunks, cap));
+    p.grid = (uint32_t)(main_groups + helpers);
+    a.main_groups = (uint32_t)main_groups;
+    a.helper_below_mhz = helper_mode() == 1 ? 0xFFFFFFFFu : kHelperBelowMHz;
     // one grid trip advances every lane-word by grid chunks
     a.stride_mul2 = 2u * lcg::powmod(lcg::A, ((uint64_t)p.grid * chunk) % lcg::PERIOD);
     return p;
@@ -436,7 +464,7 @@ int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_of
     }
     g_stats.gpu_launches.fetch_add(1, std::memory_order_relaxed);
     t_last_launch = {modgpu_variant_kernel_name(p.variant), p.variant, p.grid, modgpu_variant_block(p.variant),
-                     modgpu_variant_chunk_bytes(p.variant), n};
+                     modgpu_variant_chunk_bytes(p.variant), n, p.variant == CYCLE_QUEUE ? p.args.main_groups : p.grid};
     return MODGPU_OK;
 }
 
@@ -1030,6 +1058,8 @@ void modgpu_debug_set_launch(int variant, uint32_t grid_cap)
 
 void modgpu_debug_set_pinned_mode(int mode) { g_pinned_mode.store(mode, std::memory_order_relaxed); }
 void modgpu_debug_set_staged_mode(int mode) { g_staged_mode.store(mode, std::memory_order_relaxed); }
+
+void modgpu_debug_set_helpers(int mode) { g_helper_mode.store(mode >= 0 && mode <= 2 ? mode : 0, std::memory_order_relaxed); }
 
 void modgpu_debug_set_queue_ring(uint32_t lines)
 {

@@ -39,6 +39,7 @@ def hooks(lib):
             M.debug_set_pinned_mode(0)
             M.debug_set_staged_mode(0)
             M.debug_set_queue_ring(0)
+            M.debug_set_helpers(0)
             M.debug_inject_failures(0)
 
 

@@ -45,6 +45,7 @@ def gpu_t(gpu):
             gpu.debug_set_pinned_mode(0)
             gpu.debug_set_staged_mode(0)
             gpu.debug_set_queue_ring(0)
+            gpu.debug_set_helpers(0)
             gpu.debug_inject_failures(0)
     assert gpu.active_flavour() == "shipped"
 
@@ -415,7 +416,8 @@ def test_queue_kernel_soak(gpu_t, oracle):
     for _ in range(2000):
         dbuf.cycle(0xC64EED30, n=n, offset=base, stream_off=999)
     dbuf.sync()
-    assert gpu.last_launch()["variant"] == 2 and gpu.last_launch()["grid"] == 200
+    info = gpu.last_launch()
+    assert info["variant"] == 2 and info["main_groups"] == 200 and info["grid"] == 256  # 25 per 32 CUs stream, the other 56 CUs get a helper workgroup
     assert np.array_equal(dbuf.download(), pt)
     try:
         for grid in (1, 2, 3, 7, 64, 199, 256):
@@ -424,7 +426,8 @@ def test_queue_kernel_soak(gpu_t, oracle):
                 dbuf.cycle(0xC64EED30, n=n, offset=base, stream_off=999)
                 dbuf.cycle(0xC64EED30, n=n, offset=base, stream_off=999)
             dbuf.sync()
-            assert gpu.last_launch()["grid"] == min(grid, 200)  # the cap only lowers the library's own choice
+            info = gpu.last_launch()  # the cap only lowers the library's own choice; a grid capped below the CU count has no helpers
+            assert info["main_groups"] == min(grid, 200) and info["grid"] == (256 if grid >= 256 else min(grid, 200)), info
             assert np.array_equal(dbuf.download(), pt), grid
     finally:
         gpu.debug_set_launch(None, 0)
@@ -436,6 +439,49 @@ def test_queue_kernel_soak(gpu_t, oracle):
         ln = min(1 << 20, n - off)
         assert np.array_equal(got[base + off:base + off + ln] ^ pt[base + off:base + off + ln], oracle.keystream(0xC64EED30, ln, 999 + off)), off
     dbuf.free()
+
+
+@pytest.mark.parametrize("mode", [1, 2, 0], ids=["helpers_join", "no_helpers", "by_the_clock"])
+def test_helper_workgroups_of_the_queue_shape(gpu_t, oracle, mode):
+    """The work-queue shape launches a helper workgroup on every CU its 25-per-32 main workgroups leave idle; a helper measures
+    the shader clock when it starts and joins the ticket queue only while the clock is low (the first ~10 ms after load onset,
+    where the kernel is bound by its arithmetic: profiles/r03_first_pass.txt), else it leaves at once.  Which branch a helper
+    takes depends on the chip's state, so both are forced here (always join / no helpers launched) beside the shipped
+    decision, on the full-size grid and on small forced grids with ragged ends -- whole-buffer compare, odd and even passes."""
+    gpu = gpu_t
+    gpu.debug_set_helpers(mode)
+    n, base = (320 << 20) + 4099, 20
+    pt = oracle.splitmix_bytes(n + 64, 77 + mode)
+    d = gpu.DeviceBuffer(n + 64)
+    d.upload(pt)
+    want = pt.copy()
+    oracle.cycle_at(want[base:base + n], 0x90CFC0AB, 31337)
+    for k in range(1, 5):
+        d.cycle(0x90CFC0AB, n=n, offset=base, stream_off=31337)
+        d.sync()
+        info = gpu.last_launch()
+        assert info["variant"] == 2 and info["main_groups"] == 200 and info["grid"] == (200 if mode == 2 else 256), info
+        assert np.array_equal(d.download(), want if k % 2 else pt), (mode, k)
+    d.free()
+    if mode == 1:  # helpers on forced small grids: main + helpers in the product's proportion, few chunks, ragged ends
+        rng = np.random.default_rng(5)
+        cap = (12 << 20) + 4096
+        d = gpu.DeviceBuffer(cap)
+        for grid in (1, 2, 3, 8, 25, 64):
+            gpu.debug_set_launch("queue", grid)
+            for n in (65536 * 3 + 5, 65536 * 7 - 16, 65536 * 40 + 77, int(rng.integers(1 << 20, 11 << 20))):
+                base = int(rng.integers(0, 70000))
+                whole = rng.integers(0, 256, size=n + 128, dtype=np.uint8)
+                lo = max(0, base - 64)
+                d.upload(whole, offset=lo)
+                d.cycle(0xC64EED30, n=n, offset=base, stream_off=n)
+                d.sync()
+                info = gpu.last_launch()
+                assert info["variant"] == 2 and info["grid"] > info["main_groups"] >= 1 and info["main_groups"] <= grid, info
+                w = whole.copy()
+                oracle.cycle_at(w[base - lo:base - lo + n], 0xC64EED30, n)
+                assert np.array_equal(d.download(n + 128, offset=lo), w), (grid, n, base)
+        d.free()
 
 
 @pytest.mark.parametrize("ring", [1, 2, 0], ids=["ring1", "ring2", "ring4096"])

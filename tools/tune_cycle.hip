@@ -179,9 +179,13 @@ static int dvfs_main(uint64_t n, int launches)
     CHECK(hipMemset(a.queue, 0, 64));
     a.head_ptr = buf; a.body = buf; a.body_words = n / 16; a.tail_ptr = buf + n;
     a.base_head = a.base_body = a.base_tail = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
-    struct Shape { const char *name; void (*launch)(const CycleArgs &, uint32_t, hipStream_t); uint32_t grid; };
+    struct Shape { const char *name; void (*launch)(const CycleArgs &, uint32_t, hipStream_t); uint32_t grid; uint32_t main = 0; uint32_t below = 0; };
     const Shape shapes[] = {
-        {"queue 64 KiB, FULL alg 2 (carry from the fold), grid 200", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 200},
+        {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers joining below 1750 MHz (shipped)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1750},
+        {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers joining below 1900 MHz", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1900},
+        {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers joining below 1600 MHz", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1600},
+        {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers that never join", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1},
+        {"queue 64 KiB, FULL alg 2 (carry from the fold), grid 200, no helpers", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 200},
         {"queue 64 KiB, FULL alg 2, grid 208", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 208},
         {"queue 64 KiB, FULL alg 2, grid 216", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 216},
         {"queue 64 KiB, FULL alg 2, grid 224", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 224},
@@ -194,6 +198,8 @@ static int dvfs_main(uint64_t n, int launches)
     printf("bytes=%llu launches=%d: per launch  ms | GB/s (2*bytes/t) | shader MHz (mean of 10 us samples)\n", (unsigned long long)n, launches);
     for (const Shape &sh : shapes) {
         a.stride_mul2 = 2u * lcg::powmod(lcg::A, ((uint64_t)sh.grid * 65536) % lcg::PERIOD);
+        a.main_groups = sh.main;
+        a.helper_below_mhz = sh.below;
         CHECK(hipDeviceSynchronize());
         usleep(300000);
         CHECK(hipMemsetAsync(d_probe, 0, samples * 16, pst));
