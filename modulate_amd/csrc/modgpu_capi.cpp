@@ -220,7 +220,7 @@ uint32_t large_grid()
     return cus[dev];
 }
 // Work-queue shape: every launch needs a {ticket, done} pair that is zero when it starts; the kernel's last
-// workgroup zeroes it again and then signs off in a host-visible word, so a per-device ring of pairs (one 64-byte
+// workgroup zeroes it again and then signs off in a host-visible word, so a per-device ring of pairs (one 128-byte
 // line each) is allocated and cleared once.  Two launches must never share a pair while either runs (their
 // tickets would interleave: chunks skipped in one, done twice in neither -- wrong bytes, no error), so
 //   * an eager launch takes a ring line only if the line's previous user has signed off (done[line] ==
@@ -231,9 +231,13 @@ uint32_t large_grid()
 //     separate grow-only pool that is never handed out again (pool empty: static shape).
 constexpr uint32_t kQueueRing = 4096; // eager lines: more than any caller keeps in flight (a launch that finds none free still has the static shape)
 constexpr uint32_t kGraphPool = 1024; // lines owned by captured launches, for the life of the process
+// A pair has a 128-byte line to itself: that is the L2 line size, and two launches in flight must not have their ticket
+// counters in one line (nor may anything that is polled sit there: profiles/r03_tune_dvfs.txt, stand-by helpers -- a reader in
+// the ticket counter's line cost 15 %)
+constexpr uint32_t kLineWords = 32;
 struct QueueRing {
     std::mutex mu;
-    std::atomic<uint32_t *> base{nullptr}; // device: (kQueueRing + kGraphPool) lines of 16 words, all zero between launches
+    std::atomic<uint32_t *> base{nullptr}; // device: (kQueueRing + kGraphPool) lines of kLineWords words, all zero between launches
     uint32_t *done = nullptr;              // host-coherent pinned memory: one word per ring line, written by the kernel
     uint32_t *done_dev = nullptr;          // the same words as the device addresses them
     uint32_t issued[kQueueRing] = {};      // sequence number given to the line's latest user   (under mu)
@@ -272,7 +276,7 @@ bool queue_ring_create(QueueRing &r, hipStream_t stream)
     (void)hipThreadExchangeStreamCaptureMode(&mode);
     uint32_t *lines = nullptr, *done = nullptr, *done_dev = nullptr;
     hipStream_t st = nullptr;
-    const size_t bytes = (size_t)(kQueueRing + kGraphPool) * 64;
+    const size_t bytes = (size_t)(kQueueRing + kGraphPool) * kLineWords * sizeof(uint32_t);
     bool ok = hipMalloc(reinterpret_cast<void **>(&lines), bytes) == hipSuccess &&
               hipHostMalloc(reinterpret_cast<void **>(&done), kQueueRing * sizeof(uint32_t),
                             hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
@@ -314,7 +318,7 @@ QueuePair queue_pair(hipStream_t stream)
             g_queue_graph_full.fetch_add(1, std::memory_order_relaxed);
             return q;
         }
-        q.pair = base + (size_t)(kQueueRing + r.graph_used++) * 16;
+        q.pair = base + (size_t)(kQueueRing + r.graph_used++) * kLineWords;
         g_queue_graph.fetch_add(1, std::memory_order_relaxed);
         return q;
     }
@@ -324,7 +328,7 @@ QueuePair queue_pair(hipStream_t stream)
         // (an acquire load of a word the GPU writes: what follows is ordered behind seeing the sign-off)
         if (__atomic_load_n(&r.done[line], __ATOMIC_ACQUIRE) != r.issued[line]) continue; // its latest user has not signed off yet
         r.next = line + 1;
-        q.pair = base + (size_t)line * 16;
+        q.pair = base + (size_t)line * kLineWords;
         q.done = r.done_dev + line;
         q.seq = ++r.issued[line];
         q.line = (int)line;
@@ -497,7 +501,7 @@ void prepare_device()
             a.body = a.head_ptr = a.tail_ptr = scratch;
             a.base_head = a.base_body = a.base_tail = 1;
             a.stride_mul2 = 2;
-            a.queue = g_queue_ring[dev].base.load(std::memory_order_acquire) + (size_t)(kQueueRing + kGraphPool - 1) * 16;
+            a.queue = g_queue_ring[dev].base.load(std::memory_order_acquire) + (size_t)(kQueueRing + kGraphPool - 1) * kLineWords;
             for (int v = 0; v < kCycleVariants; ++v) (void)modgpu_launch_cycle(a, v, 1, st);
         }
         (void)hipStreamSynchronize(st);
