@@ -46,6 +46,7 @@
  *                                against one host thread; 0 = always the GPU)
  *     MODGPU_HOST_ISA=name       host-loop body: generic | avx2 | avx512 (default: the best the CPU runs)
  *     MODGPU_HOST_THREADS=n      most host threads one host-loop call may use (default min(cores, 32))
+ *     MODGPU_HOST_SPREAD=0       do not give each host-loop worker thread a CPU of its own (leave placement to the scheduler)
  *     MODGPU_DEVICE_ALIAS=n      see modgpu_device_count
  *     MODGPU_HOST_PIPES / _CHUNK_MB / _ZEROCOPY_KB / _RING   staging pipeline of the host-buffer routes
  *     MODGPU_NUMA=0              do not place host memory and worker threads next to their GPU
