@@ -374,3 +374,9 @@ def test_bench_nccl_branch_single_rank(host):
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["config"]["bit_exact_check"].startswith("pass")
     assert out["roofline"]["kernel"].startswith("modgpu_cycle_queue_kernel<4, 1024,")
+    # the first-pass figures beside the steady state, and which launches the events bracket
+    fp = out["roofline"]["first_pass"]
+    assert fp["part"]["bytes"] == 320 << 20 and fp["part"]["ms"] > 0 and len(fp["ms_of_launches_1_to_12"]) == 12
+    assert fp["slowest_of_launches_1_to_12"]["ms"] == max(fp["ms_of_launches_1_to_12"])
+    assert out["roofline"]["timed_launches"] == [14 + 2 * 1, 14 + 2 * 1 + 2 * 3]
+    assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["bound"] == "hbm" and out["roofline"]["peak"] == 8000.0
