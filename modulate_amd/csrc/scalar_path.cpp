@@ -21,6 +21,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -230,7 +231,8 @@ void modgpu_scalar_cycle(uint8_t *buf, uint64_t n, int32_t key, uint64_t stream_
     const uint64_t per = ((n + threads - 1) / threads + 63) & ~63ull;
     static const Spread spread;
     const int here = sched_getcpu();
-    size_t next_cpu = 0;
+    static std::atomic<size_t> rotate{0}; // concurrent calls start their workers on different CPUs instead of all on the first ones
+    size_t next_cpu = rotate.fetch_add((size_t)threads, std::memory_order_relaxed);
     auto worker_cpu = [&]() -> int { // the next allowed CPU that is not the caller's; -1: leave it to the scheduler
         if (spread.cpus.size() < threads) return -1;
         if (spread.cpus[next_cpu % spread.cpus.size()] == here) ++next_cpu;
