@@ -55,6 +55,10 @@ int modgpu_cycle_scalar_host_isa(uint8_t *host_buf, uint64_t n, int32_t key, uin
  * *node = NUMA node of PCI function `bdf` (-1 unknown), cpus[0..return) = that node's CPUs (at most max_cpus). */
 int modgpu_numa_probe(const char *sysfs_root, const char *bdf, int *node, int *cpus, int max_cpus);
 
+/* modgpu_host_alloc_near with the node named outright (measurement: the same kernel on memory next to the GPU and on the other
+ * socket's, bin/modbench --numa).  MODGPU_ERR_INVALID if mbind refuses the node.  Free with modgpu_host_free. */
+int modgpu_host_alloc_on_node(void **host_ptr, uint64_t n, int node);
+
 /* Work-queue bookkeeping since load: out[0] = eager launches that got a ring line, out[1] = eager launches that
  * found every line busy and took the static shape, out[2] = captured launches that got a line of their own,
  * out[3] = captured launches that found the pool empty (static shape). */

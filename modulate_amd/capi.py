@@ -83,6 +83,7 @@ TESTING_EXPORTS = {
     "modgpu_host_tunables": (None, [ctypes.POINTER(_u64)]),
     "modgpu_cycle_scalar_host_isa": (_int, [_vp, _u64, _i32, _u64, ctypes.c_char_p]),
     "modgpu_queue_stats": (None, [ctypes.POINTER(_u64)]),
+    "modgpu_host_alloc_on_node": (_int, [ctypes.POINTER(_vp), _u64, _int]),
     "modgpu_testing_hooks": (_int, []),
     "modgpu_numa_probe": (_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_int), ctypes.POINTER(_int), _int]),
 }

@@ -12,6 +12,8 @@
 //       crossover MODGPU_MIN_GPU_BYTES should sit at; per-core and all-core GB/s of every host-loop body.
 //   modbench --alloc
 //       what the part buffer costs: modgpu_host_alloc against modgpu_host_alloc_parts, and the kernel's rate on each.
+//   modbench --numa
+//       the kernel across PCIe on page-locked memory of each NUMA node (the GPU's own and the others).
 //   modbench --files DIR [--bytes B]...
 //       the file routes (modgpu_cycle_file / _file_to_host / _host_to_file) beside their two ceilings: the same
 //       pread / pwrite schedule with the cipher skipped (I/O only) and the cipher with the I/O skipped (GPU only).
@@ -348,6 +350,27 @@ int Alloc( uint64_t n, int nParts )
     return 0;
 }
 
+// ---- --numa: does it matter which socket's memory the kernel works on across PCIe? ---------------------------------------
+int Numa( uint64_t n )
+{
+    const int near = modgpu_device_numa_node( 0 );
+    std::printf( "== page-locked memory by NUMA node, %.0f MiB, GPU 0 on node %d: modgpu_cycle_host in place (kernel across PCIe), best of 5; and a 1-thread memset of it\n", n / 1048576.0, near );
+    for( int node = 0; node < 8; ++node )
+    {
+        void* p = nullptr;
+        if( modgpu_host_alloc_on_node( &p, n, node ) != MODGPU_OK ) { if( node < 2 ) std::printf( "   node %d: %s\n", node, modgpu_last_error() ); continue; }
+        std::memset( p, 0x22, n );
+        (void)modgpu_cycle_host( static_cast< uint8_t* >( p ), n, kKey, 0, 0 );
+        double best = 1e30, bestSet = 1e30;
+        for( int i = 0; i < 5; ++i ) { const double t0 = Now(); (void)modgpu_cycle_host( static_cast< uint8_t* >( p ), n, kKey, 0, 0 ); best = std::min( best, Now() - t0 ); }
+        for( int i = 0; i < 3; ++i ) { const double t0 = Now(); std::memset( p, i, n ); bestSet = std::min( bestSet, Now() - t0 ); }
+        std::printf( "   node %d%s  kernel across PCIe %6.2f GB/s   pinned: %s   host memset %5.1f GB/s\n", node, node == near ? " (the GPU's)" : "            ", n / best / 1e9,
+                     modgpu_host_is_pinned( p, n ) ? "yes" : "no", n / bestSet / 1e9 );
+        TRY( modgpu_host_free( p ) );
+    }
+    return 0;
+}
+
 std::vector< int > IntList( const char* s )
 {
     std::vector< int > v;
@@ -380,6 +403,7 @@ int main( int argc, char** argv )
         else if( a == "--warmup" ) warmup = std::atoi( next() );
         else if( a == "--hostcall" ) mode = "hostcall";
         else if( a == "--alloc" ) { mode = "alloc"; partBytes = 3291444381ull; nParts = 8; }
+        else if( a == "--numa" ) { mode = "numa"; partBytes = 1ull << 30; }
         else if( a == "--files" ) { mode = "files"; dir = next(); }
         else if( a == "--bytes" ) fileSizes.push_back( std::strtoull( next(), nullptr, 0 ) );
         else positional.push_back( argv[ i ] );
@@ -389,6 +413,7 @@ int main( int argc, char** argv )
     if( mode == "parts" ) return nParts > 0 ? Parts( nParts, devices, partBytes, steps, std::max( warmup, 1 ) ) : 1;
     if( mode == "files" ) return Files( dir, fileSizes );
     if( mode == "alloc" ) return Alloc( partBytes, nParts > 0 ? nParts : 8 );
+    if( mode == "numa" ) return Numa( partBytes );
     const uint64_t n = positional.size() > 0 ? std::strtoull( positional[ 0 ], nullptr, 0 ) : ( 1ull << 32 );
     return Classic( n, positional.size() > 1 ? std::atoi( positional[ 1 ] ) : 20, positional.size() > 2 ? std::atoi( positional[ 2 ] ) : 3,
                     positional.size() > 3 ? std::atoi( positional[ 3 ] ) : 0 );

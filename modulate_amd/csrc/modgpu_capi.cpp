@@ -840,6 +840,30 @@ int modgpu_host_alloc_near(void **host_ptr, uint64_t n, int device)
     });
 }
 
+int modgpu_host_alloc_on_node(void **host_ptr, uint64_t n, int node)
+{
+    return guarded([&]() -> int {
+        if (!host_ptr || node < 0) return fail(MODGPU_ERR_INVALID, "null out pointer or negative node");
+        *host_ptr = nullptr;
+        const uint64_t bytes = n ? n : 1;
+        void *p = numa::reserve(bytes);
+        if (!p) return fail(MODGPU_ERR_INVALID, "out of host memory");
+        if (numa::prefer_node(p, bytes, node) != 0) {
+            numa::release(p, bytes);
+            return fail(MODGPU_ERR_INVALID, "mbind refused that node");
+        }
+        numa::prefault(p, bytes, kPrefaultThreads, "/sys", -1);
+        bool pinned = physical_count() > 0 && hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess;
+        if (!pinned) (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lock(g_host_mu);
+            g_host_ranges.push_back({reinterpret_cast<uintptr_t>(p), bytes, pinned, HostKind::Placed});
+        }
+        *host_ptr = p;
+        return MODGPU_OK;
+    });
+}
+
 int modgpu_device_numa_node(int device)
 {
     if (device < 0 || device >= logical_count()) return -1;
