@@ -270,6 +270,14 @@ def test_placed_host_memory_without_gpu_is_plain_memory(modgpu):
         pb.array[:] = 3
         assert int(pb.array.sum()) == 900_000
         pb.free()
+    # the measurement hook that names the node outright: node 0 exists everywhere; a node that does not exist is refused or ignored
+    import ctypes
+    p = ctypes.c_void_p()
+    L = modgpu.lib()
+    assert L.modgpu_host_alloc_on_node(ctypes.byref(p), 1 << 20, 0) == 0 and p.value
+    ctypes.memset(p, 0x5A, 1 << 20)
+    assert L.modgpu_host_is_pinned(p, 1 << 20) == 0 and L.modgpu_host_free(p) == 0
+    assert L.modgpu_host_alloc_on_node(ctypes.byref(p), 4096, -1) == 1
 
 
 def test_require_gpu_forbids_the_host_loop(modgpu):
