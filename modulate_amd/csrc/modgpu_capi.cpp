@@ -314,7 +314,7 @@ QueuePair queue_pair(hipStream_t stream)
     }
     std::lock_guard<std::mutex> lock(r.mu);
     if (cap != hipStreamCaptureStatusNone) { // the graph keeps its line for good
-        if (r.graph_used >= kGraphPool - 1) { // (the last line belongs to prepare_device's empty launch)
+        if (r.graph_used >= kGraphPool) {
             g_queue_graph_full.fetch_add(1, std::memory_order_relaxed);
             return q;
         }
@@ -493,17 +493,13 @@ void prepare_device()
     hipStream_t st = nullptr;
     uint8_t *scratch = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&scratch), 4096) == hipSuccess) {
-        // one empty launch of every shape: the code object is loaded and each kernel has been through its first dispatch
-        // (the first launch of a kernel costs tens of microseconds more than the following ones).  The queue shape's
-        // empty launch counts itself in and out on the pool's last line, which is never handed out.
-        if (queue_ring_create(g_queue_ring[dev], st)) {
-            CycleArgs a{};
-            a.body = a.head_ptr = a.tail_ptr = scratch;
-            a.base_head = a.base_body = a.base_tail = 1;
-            a.stride_mul2 = 2;
-            a.queue = g_queue_ring[dev].base.load(std::memory_order_acquire) + (size_t)(kQueueRing + kGraphPool - 1) * kLineWords;
-            for (int v = 0; v < kCycleVariants; ++v) (void)modgpu_launch_cycle(a, v, 1, st);
-        }
+        // the ticket ring, and one empty launch: the code object all three shapes live in is loaded by it
+        (void)queue_ring_create(g_queue_ring[dev], st);
+        CycleArgs a{};
+        a.body = a.head_ptr = a.tail_ptr = scratch;
+        a.base_head = a.base_body = a.base_tail = 1;
+        a.stride_mul2 = 2;
+        (void)modgpu_launch_cycle(a, CYCLE_SMALL, 1, st);
         (void)hipStreamSynchronize(st);
     }
     (void)hipGetLastError();
