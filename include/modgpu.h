@@ -50,6 +50,7 @@
  *     MODGPU_DEVICE_ALIAS=n      see modgpu_device_count
  *     MODGPU_HOST_PIPES / _CHUNK_MB / _ZEROCOPY_KB / _RING   staging pipeline of the host-buffer routes
  *     MODGPU_NUMA=0              do not place host memory and worker threads next to their GPU
+ *     MODGPU_HELPER_BELOW_MHZ=n  shader clock below which the helper workgroups of a large launch join in (default 1850; 0 = never)
  */
 #ifndef MODGPU_H
 #define MODGPU_H

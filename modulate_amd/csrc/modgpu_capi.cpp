@@ -349,8 +349,19 @@ void queue_pair_unused(const QueuePair &q)
 }
 
 // Helper workgroups of the work-queue shape join while the shader clock is below this: with the three-instruction keystream
-// the 25-per-32 main workgroups stay HBM-bound down to ~1.7 GHz (profiles/r03_first_pass.txt: 1 711 MHz 6.97 TB/s, 1 645 6.87, 1 579 6.69)
-constexpr uint32_t kHelperBelowMHz = 1750;
+// the 25-per-32 main workgroups stay HBM-bound down to ~1.7 GHz (profiles/r03_first_pass.txt: 1 711 MHz 6.97 TB/s, 1 645 6.87,
+// 1 579 6.69), and the steady-state clock sits at 2.0-2.2 GHz.  Thresholds from 1 600 to 1 950 MHz measure within run-to-run
+// spread of each other, back to back (r03_tune_dvfs.txt) and with host gaps between launches (bench.py's first-pass series,
+// A/B'd on one box: 1 850 a little better than 1 750 there, steady state identical); 1 850 keeps ~150 MHz off the steady state.
+constexpr uint32_t kHelperBelowMHzDefault = 1850;
+uint32_t helper_below_mhz() // MODGPU_HELPER_BELOW_MHZ (read once; 0 = helpers never join)
+{
+    static const uint32_t v = [] {
+        const char *e = std::getenv("MODGPU_HELPER_BELOW_MHZ");
+        return e && *e ? (uint32_t)std::strtoul(e, nullptr, 0) : kHelperBelowMHzDefault;
+    }();
+    return v;
+}
 #ifdef MODGPU_TESTING_HOOKS
 std::atomic<int> g_helper_mode{0}; // modgpu_debug_set_helpers: 0 by the clock, 1 always join, 2 no helper workgroups
 int helper_mode() { return g_helper_mode.load(std::memory_order_relaxed); }
@@ -422,7 +433,7 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
     // ... at the clock the chip normally runs at.  While power management holds the shader clock low (the first ~10 ms after
     // load onset) the kernel is bound by its arithmetic instead, and the CUs left idle are worth more than the tidy memory
     // pattern: they get a HELPER workgroup each, which measures the clock when it starts and joins the ticket queue only
-    // while it is below kHelperBelowMHz (cycle_kernel_impl.h; profiles/r03_first_pass.txt, r03_tune_dvfs.txt).
+    // while it is below MODGPU_HELPER_BELOW_MHZ (default 1850; cycle_kernel_impl.h; profiles/r03_first_pass.txt, r03_tune_dvfs.txt).
     uint64_t helpers = 0;
     const uint32_t grid_cap = forced_grid_cap();
     if (p.variant == CYCLE_QUEUE) {
@@ -441,7 +452,7 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
     const uint64_t main_groups = std::max<uint64_t>(1, std::min<uint64_t>(chunks, cap));
     p.grid = (uint32_t)(main_groups + helpers);
     a.main_groups = (uint32_t)main_groups;
-    a.helper_below_mhz = helper_mode() == 1 ? 0xFFFFFFFFu : kHelperBelowMHz;
+    a.helper_below_mhz = helper_mode() == 1 ? 0xFFFFFFFFu : helper_below_mhz();
     // one grid trip advances every lane-word by grid chunks
     a.stride_mul2 = 2u * lcg::powmod(lcg::A, ((uint64_t)p.grid * chunk) % lcg::PERIOD);
     return p;

@@ -181,7 +181,8 @@ static int dvfs_main(uint64_t n, int launches)
     a.base_head = a.base_body = a.base_tail = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
     struct Shape { const char *name; void (*launch)(const CycleArgs &, uint32_t, hipStream_t); uint32_t grid; uint32_t main = 0; uint32_t below = 0; };
     const Shape shapes[] = {
-        {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers joining below 1750 MHz (shipped)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1750},
+        {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers joining below 1850 MHz (shipped)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1850},
+        {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers joining below 1750 MHz", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1750},
         {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers joining below 1900 MHz", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1900},
         {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers joining below 1600 MHz", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1600},
         {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers that never join", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1},
