@@ -224,7 +224,7 @@ uint32_t large_grid()
 // line each) is allocated and cleared once.  Two launches must never share a pair while either runs (their
 // tickets would interleave: chunks skipped in one, done twice in neither -- wrong bytes, no error), so
 //   * an eager launch takes a ring line only if the line's previous user has signed off (done[line] ==
-//     issued[line], a plain read of host-coherent memory: no HIP call, nothing extra on the stream); if every
+//     issued[line], an acquire load of host-coherent memory: no HIP call, nothing extra on the stream); if every
 //     line is busy the launch takes the static streaming shape, which needs no pair;
 //   * a launch that is being captured into a hipGraph is baked into the graph together with its pair, and may
 //     be replayed at any later time, so it never draws from the ring: it gets a line of its own from a
