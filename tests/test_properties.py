@@ -31,6 +31,23 @@ def test_host_loop_equals_oracle(modgpu, oracle, key, n, off, lead, seed):
 
 
 @needs_host_loop
+@settings(max_examples=150, **COMMON)
+@given(isa=st.sampled_from(["generic", "avx2", "avx512"]), key=keys, n=st.integers(0, 700), off=offsets,
+       lead=st.integers(0, 70), seed=st.integers(0, 1 << 30))
+def test_each_host_loop_body_equals_oracle(modgpu, oracle, isa, key, n, off, lead, seed):
+    """The three bodies of scalar_path.cpp by name, at any alignment against their 16/32/64-byte blocks."""
+    whole = oracle.splitmix_bytes(n + lead + 9, seed)
+    got, want = whole.copy(), whole.copy()
+    try:
+        modgpu.cycle_scalar_host_isa(got[lead:lead + n], key, isa, off)
+    except modgpu.ModGpuError as e:
+        assert e.code == 1  # this CPU does not run that body
+        return
+    oracle.cycle_at(want[lead:lead + n], key, off)
+    assert np.array_equal(got, want)
+
+
+@needs_host_loop
 @settings(max_examples=60, **COMMON)
 @given(key=keys, n=st.integers(1, 5000), off=offsets, cut=st.floats(0, 1), seed=st.integers(0, 1 << 30))
 def test_involution_and_split_stream(modgpu, oracle, key, n, off, cut, seed):
