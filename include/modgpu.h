@@ -126,11 +126,15 @@ int modgpu_cycle_scalar_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_
 int modgpu_cycle_auto_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, int device);
 
 /* Header framing of CArk::Load (CArk.cpp:328-339) and Decode (Modulate.cpp:475-486):
- * LE u32 magic at hdr[0..3] selects the key, the cipher covers hdr[4..size).  Host buffer. */
+ * LE u32 magic at hdr[0..3] selects the key, the cipher covers hdr[4..size).  Host buffer; the cipher call is
+ * Cycle's, so the engine is chosen exactly as by modgpu_cycle_auto_host (headers are at most 512 KiB,
+ * CArk.cpp:911-912: the host loop unless MODGPU_REQUIRE_GPU=1 or MODGPU_MIN_GPU_BYTES says otherwise).
+ * An unknown magic is MODGPU_ERR_MAGIC before anything is touched. */
 int modgpu_hdr_decrypt_host(uint8_t *hdr, uint64_t size, int device);
 
 /* Header framing of SaveArk (CArk.cpp:914-915, 1135-1136): stores the platform magic at
- * hdr[0..3] (ps4 != 0 -> PS4) and encrypts hdr[4..size) with the platform key.  Host buffer. */
+ * hdr[0..3] (ps4 != 0 -> PS4) and encrypts hdr[4..size) with the platform key.  Host buffer; engine as above;
+ * on failure the buffer is as it was. */
 int modgpu_hdr_encrypt_host(uint8_t *hdr, uint64_t size, int ps4, int device);
 
 /* Part-level sharding beside CArk::LoadArkData / lSaveArk (CArk.cpp:723-758, 845-899): part i

@@ -616,30 +616,35 @@ int modgpu_cycle_scalar_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_
     return guarded([&]() -> int { return scalar_impl(host_buf, n, key, stream_off); });
 }
 
+// What CEncryptionCycler::Cycle does with a caller-owned host buffer -- shared by modgpu_cycle_auto_host and the
+// header framing of Cycle's call sites (modgpu_hdr_*_host).
+static int cycle_auto_impl(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, int device)
+{
+    // `if (n < threshold || !gpu_ok) cpu_loop(); else ...`.  The reference's call sites pass headers
+    // (CArk.cpp:338-339, 1135-1136, Modulate.cpp:485-486; <= 512 KiB by CArk.cpp:911-912): below the measured
+    // crossover the host loop is the faster engine.  MODGPU_REQUIRE_GPU=1 keeps every size on the kernel.
+    if (n < min_gpu_bytes() && !gpu_required()) {
+        int rc = scalar_impl(host_buf, n, key, stream_off);
+        if (rc == MODGPU_OK && n) g_stats.auto_small.fetch_add(1, std::memory_order_relaxed);
+        return rc;
+    }
+    bool touched = false;
+    int rc = cycle_host_impl(host_buf, n, key, stream_off, device, &touched);
+    if (rc == MODGPU_OK || rc == MODGPU_ERR_INVALID) return rc;
+    // No GPU, or the GPU attempt failed.  The reference's Cycle cannot fail: finish on the host --
+    // unless the caller forbade that, or the failed attempt may already have written part of the
+    // result into host_buf (starting over would cycle those bytes twice).
+    if (gpu_required() || touched) return rc;
+    const std::string why = t_err;
+    rc = scalar_impl(host_buf, n, key, stream_off);
+    if (rc == MODGPU_OK) g_stats.auto_fallbacks.fetch_add(1, std::memory_order_relaxed);
+    else t_err = why;
+    return rc;
+}
+
 int modgpu_cycle_auto_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, int device)
 {
-    return guarded([&]() -> int {
-        // `if (n < threshold || !gpu_ok) cpu_loop(); else ...`.  The reference's call sites pass headers
-        // (CArk.cpp:338-339, 1135-1136, Modulate.cpp:485-486; <= 512 KiB by CArk.cpp:911-912): below the measured
-        // crossover the host loop is the faster engine.  MODGPU_REQUIRE_GPU=1 keeps every size on the kernel.
-        if (n < min_gpu_bytes() && !gpu_required()) {
-            int rc = scalar_impl(host_buf, n, key, stream_off);
-            if (rc == MODGPU_OK && n) g_stats.auto_small.fetch_add(1, std::memory_order_relaxed);
-            return rc;
-        }
-        bool touched = false;
-        int rc = cycle_host_impl(host_buf, n, key, stream_off, device, &touched);
-        if (rc == MODGPU_OK || rc == MODGPU_ERR_INVALID) return rc;
-        // No GPU, or the GPU attempt failed.  The reference's Cycle cannot fail: finish on the host --
-        // unless the caller forbade that, or the failed attempt may already have written part of the
-        // result into host_buf (starting over would cycle those bytes twice).
-        if (gpu_required() || touched) return rc;
-        const std::string why = t_err;
-        rc = scalar_impl(host_buf, n, key, stream_off);
-        if (rc == MODGPU_OK) g_stats.auto_fallbacks.fetch_add(1, std::memory_order_relaxed);
-        else t_err = why;
-        return rc;
-    });
+    return guarded([&]() -> int { return cycle_auto_impl(host_buf, n, key, stream_off, device); });
 }
 
 int modgpu_hdr_decrypt_host(uint8_t *hdr, uint64_t size, int device)
@@ -650,7 +655,7 @@ int modgpu_hdr_decrypt_host(uint8_t *hdr, uint64_t size, int device)
         if (magic != MODGPU_MAGIC_PS3 && magic != MODGPU_MAGIC_PS4)
             return fail(MODGPU_ERR_MAGIC, "unknown header magic");
         uint32_t key = magic == MODGPU_MAGIC_PS3 ? MODGPU_KEY_PS3 : MODGPU_KEY_PS4;
-        return cycle_host_impl(hdr + 4, size - 4, (int32_t)key, 0, device, nullptr);
+        return cycle_auto_impl(hdr + 4, size - 4, (int32_t)key, 0, device);
     });
 }
 
@@ -659,7 +664,7 @@ int modgpu_hdr_encrypt_host(uint8_t *hdr, uint64_t size, int ps4, int device)
     return guarded([&]() -> int {
         if (!hdr || size < 4) return fail(MODGPU_ERR_INVALID, "header shorter than its magic");
         // cipher first: on failure the caller's buffer is left as it was
-        int rc = cycle_host_impl(hdr + 4, size - 4, (int32_t)(ps4 ? MODGPU_KEY_PS4 : MODGPU_KEY_PS3), 0, device, nullptr);
+        int rc = cycle_auto_impl(hdr + 4, size - 4, (int32_t)(ps4 ? MODGPU_KEY_PS4 : MODGPU_KEY_PS3), 0, device);
         if (rc) return rc;
         store_le32(hdr, ps4 ? MODGPU_MAGIC_PS4 : MODGPU_MAGIC_PS3);
         return MODGPU_OK;

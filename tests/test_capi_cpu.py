@@ -94,8 +94,9 @@ def test_gpu_entry_points_fail_loudly_without_gpu(modgpu):
     assert e.value.code == 2 and np.array_equal(buf, keep)
     hdr = np.zeros(64, np.uint8)
     hdr[:4] = np.frombuffer(modgpu.MAGIC_PS4.to_bytes(4, "little"), np.uint8)
-    with pytest.raises(modgpu.ModGpuError):
-        modgpu.hdr_decrypt_host(hdr)
+    if modgpu.gpu_required():  # the framing entry points follow Cycle's dispatch: only strict mode keeps them on the GPU
+        with pytest.raises(modgpu.ModGpuError):
+            modgpu.hdr_decrypt_host(hdr)
     with pytest.raises(modgpu.ModGpuError):
         modgpu.cycle_parts_host([buf], modgpu.KEY_PS4)
     with pytest.raises(modgpu.ModGpuError) as e:
@@ -184,6 +185,14 @@ def test_auto_entry_point_uses_host_loop_without_gpu(modgpu, oracle):
     assert after["scalar_calls"] == before["scalar_calls"] + 1 and after["auto_small"] == before["auto_small"] + 1
     assert after["auto_fallbacks"] == before["auto_fallbacks"]
     assert after["scalar_bytes"] == before["scalar_bytes"] + 4092 and after["gpu_calls"] == before["gpu_calls"]
+    # the framing of Cycle's call sites (CArk.cpp:328-339, 914-915) takes the same dispatch
+    framed = np.concatenate([np.zeros(4, np.uint8), body])
+    want = framed.copy()
+    assert oracle.hdr_encrypt(want, True) == 0
+    assert np.array_equal(modgpu.hdr_encrypt_host(framed, True), want)
+    assert np.array_equal(modgpu.hdr_decrypt_host(framed)[4:], body)
+    after = modgpu.path_stats()
+    assert after["auto_small"] == before["auto_small"] + 3 and after["gpu_calls"] == before["gpu_calls"]
     big = oracle.splitmix_bytes((16 << 20) + 1, 5)
     assert np.array_equal(modgpu.cycle_auto_host(big.copy(), modgpu.KEY_PS3), oracle.cycle(big.copy(), oracle.KEY_PS3))
     last = modgpu.path_stats()

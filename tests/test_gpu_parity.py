@@ -123,6 +123,7 @@ def test_golden_keystreams(gpu, oracle, golden):
 def test_config1_4k_header_framing(gpu, oracle):
     """BASELINE config 1: 4 KiB blob, magic(4) || Cycle(rest) (CArk.cpp:328-339, Modulate.cpp:475-486)."""
     body = oracle.splitmix_bytes(4092, 0x4D6F64756C617465)
+    before = gpu.path_stats()
     for ps4 in (True, False):
         a = np.concatenate([np.zeros(4, np.uint8), body])
         b = a.copy()
@@ -131,6 +132,8 @@ def test_config1_4k_header_framing(gpu, oracle):
         assert np.array_equal(a, b)
         gpu.hdr_decrypt_host(a)
         assert np.array_equal(a[4:], body)
+    after = gpu.path_stats()  # the framing follows Cycle's dispatch; MODGPU_REQUIRE_GPU=1 (conftest) keeps a header on the kernel
+    assert after["gpu_calls"] == before["gpu_calls"] + 4 and after["scalar_calls"] == before["scalar_calls"]
     with pytest.raises(gpu.ModGpuError) as e:
         gpu.hdr_decrypt_host(np.zeros(4096, np.uint8))
     assert e.value.code == 4
