@@ -101,6 +101,15 @@ def load_traffic(n_bytes, kernel, source_hash):
                                            f"separate passes, same kernel-source hash {source_hash[:12]}...)")
 
 
+def load_valu(n_bytes, kernel, source_hash):
+    """VALU utilisation of the same launches ("report VALU utilisation beside HBM %"): the `valu` object of the
+    committed PMC summary, under the same conditions as `traffic` (null otherwise)."""
+    if load_traffic(n_bytes, kernel, source_hash)[0] is None:
+        return None
+    with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as f:
+        return json.load(f).get("valu")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -267,6 +276,7 @@ def main():
                                  f"{stats['scalar_calls']} host-loop calls on rank 0"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "valu": load_valu(n, launch["kernel"], M.kernel_source_hash()),
                          "kernel": launch["kernel"], "grid": launch["grid"], "main_workgroups": launch["main_groups"], "block": launch["block"],
                          "chunk_bytes": launch["chunk_bytes"], "kernel_source_hash": M.kernel_source_hash(),
                          "ms_per_launch": round(ms_per_launch, 4), "algorithmic_bytes_per_launch": 2 * n,

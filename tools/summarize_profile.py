@@ -15,6 +15,22 @@ def find(root, pat):
     return sorted(glob.glob(os.path.join(root, "**", pat), recursive=True))
 
 
+def valu_utilisation(sq, cus=256, xcds=8):
+    """VALU utilisation beside the HBM figure.  counter() sums a dispatch's rows, so GRBM_GUI_ACTIVE is the sum
+    over the XCDs.  rocprofv3's own VALUBusy (counter_defs.yaml, gfx94x formula) prices every VALU instruction at one
+    quad-cycle (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU on gfx950); this kernel's mix is two 8-cycle v_mad_u64_u32 per
+    4-cycle instruction -- 6.6 cycles per instruction measured where the SIMDs are saturated (profiles/r03_first_pass.txt)."""
+    if not all(k in sq for k in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")):
+        return {}
+    cycles = sq["GRBM_GUI_ACTIVE"] / xcds
+    simds = 4 * cus
+    return {"valu": {"gpu_cycles_per_launch": round(cycles),
+                     "VALUBusy_pct_rocprofv3_formula": round(100 * sq["SQ_ACTIVE_INST_VALU"] / cus / cycles, 1),
+                     "issue_cycles_per_instruction_measured_saturated": 6.6,
+                     "valu_issue_pct_of_all_simds": round(100 * sq["SQ_INSTS_VALU"] * 6.6 / simds / cycles, 1),
+                     "valu_issue_pct_of_the_800_simds_of_the_main_workgroups": round(100 * sq["SQ_INSTS_VALU"] * 6.6 / 800 / cycles, 1)}}
+
+
 def main():
     root, tag = sys.argv[1], sys.argv[2]
     part_bytes = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 32
@@ -93,6 +109,7 @@ def main():
             sq[name] = v[len(v) // 2]
     if sq:
         out["sq_median_per_launch"] = sq
+        out.update(valu_utilisation(sq))
     with open(os.path.join(root, f"{tag}_pmc_summary.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
