@@ -32,7 +32,8 @@ int modgpu_time_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t st
 typedef struct modgpu_launch_info {
     const char *kernel;   /* the instantiation's name as rocprofv3 prints it, e.g.
                              "modgpu_cycle_queue_kernel<4, 1024, 1, 18, 0, 1, 0, 2, 1, 1>"; static storage */
-    int variant;          /* 0 = small shape, 1 = streaming shape (static chunk map), 2 = streaming shape fed by the work queue */
+    int variant;          /* 0 = small shape, 1 = streaming shape (static chunk map), 2 = streaming shape fed by the work queue,
+                             3 = the work-queue shape over several parts in one launch (modgpu_cycle_batch_device; `bytes` = all of them) */
     uint32_t grid;        /* workgroups launched                                                  */
     uint32_t block;       /* threads per workgroup                                                */
     uint32_t chunk_bytes; /* bytes one workgroup trip covers                                      */
@@ -61,8 +62,9 @@ int modgpu_host_alloc_on_node(void **host_ptr, uint64_t n, int node);
 
 /* Work-queue bookkeeping since load: out[0] = eager launches that got a ring line, out[1] = eager launches that
  * found every line busy and took the static shape, out[2] = captured launches that got a line of their own,
- * out[3] = captured launches that found the pool empty (static shape). */
-void modgpu_queue_stats(uint64_t out[4]);
+ * out[3] = captured launches that found the pool empty (static shape), out[4] = launches that carried several parts
+ * (modgpu_cycle_batch_device, modgpu_cycle_parts_device), out[5] = the parts they carried. */
+void modgpu_queue_stats(uint64_t out[6]);
 
 /* Identity of the device code this library carries: hex SHA-256 over the kernel sources it was
  * built from (cycle_kernel_impl.h, cycle_kernel.hip, cycle_kernel.h, lcg.h), fixed at build time.
@@ -83,6 +85,10 @@ void modgpu_debug_set_queue_ring(uint32_t lines);
  * low): 0 = decide by the clock they measure (the shipped behaviour), 1 = always join, 2 = launch none.  Lets the parity tests
  * run both branches whatever the chip's clock happens to be. */
 void modgpu_debug_set_helpers(int mode);
+
+/* modgpu_cycle_batch_device / modgpu_cycle_parts_device: 0 = several parts share a launch when together they are beyond 256 MiB
+ * or small on average (the shipped behaviour), 1 = every run of two or more non-empty parts does, 2 = one launch per part. */
+void modgpu_debug_set_batch(int mode);
 
 /* Forces the launch shape of every later launch in this process (-1 = by size, the default) and
  * caps the grid (0 = no cap).  Lets the parity tests run the streaming kernels with 1, 2, odd and

@@ -33,6 +33,7 @@ EXPORTS = {
     "modgpu_hdr_encrypt_host": (_int, [_vp, _u64, _int, _int]),
     "modgpu_cycle_parts_host": (_int, [ctypes.POINTER(_vp), ctypes.POINTER(_u64), _int, _i32, _int]),
     "modgpu_cycle_parts_device": (_int, [ctypes.POINTER(_vp), ctypes.POINTER(_u64), ctypes.POINTER(_int), _int, _i32]),
+    "modgpu_cycle_batch_device": (_int, [ctypes.POINTER(_vp), ctypes.POINTER(_u64), ctypes.POINTER(_u64), _int, _i32, _int, _vp]),
     "modgpu_cycle_file": (_int, [ctypes.c_char_p, ctypes.c_char_p, _i32, _u64, _int]),
     "modgpu_cycle_file_to_host": (_int, [ctypes.c_char_p, _u64, _vp, _u64, _i32, _u64, _int]),
     "modgpu_cycle_host_to_file": (_int, [_vp, _u64, ctypes.c_char_p, _i32, _u64, _int]),
@@ -94,6 +95,7 @@ DEBUG_EXPORTS = {
     "modgpu_debug_set_staged_mode": (None, [_int]),
     "modgpu_debug_set_queue_ring": (None, [ctypes.c_uint32]),
     "modgpu_debug_set_helpers": (None, [_int]),
+    "modgpu_debug_set_batch": (None, [_int]),
     "modgpu_debug_inject_failures": (None, [_int]),
 }
 
@@ -256,11 +258,17 @@ def debug_set_queue_ring(lines=0):
     _debug_lib().modgpu_debug_set_queue_ring(lines)
 
 
+def debug_set_batch(mode=0):
+    """Test hook: 0 several parts share a launch beyond 256 MiB in all or when small on average (shipped), 1 always, 2 never."""
+    _debug_lib().modgpu_debug_set_batch(mode)
+
+
 def queue_stats():
     """Work-queue bookkeeping since load (include/modgpu_testing.h: modgpu_queue_stats)."""
-    out = (_u64 * 4)()
+    out = (_u64 * 6)()
     lib().modgpu_queue_stats(out)
-    return {"eager": int(out[0]), "busy_fallbacks": int(out[1]), "graph": int(out[2]), "graph_pool_empty": int(out[3])}
+    return {"eager": int(out[0]), "busy_fallbacks": int(out[1]), "graph": int(out[2]), "graph_pool_empty": int(out[3]),
+            "batch_launches": int(out[4]), "batch_parts": int(out[5])}
 
 
 def testing_hooks():
@@ -374,6 +382,16 @@ def cycle_parts_device(buffers, key):
     sizes = (_u64 * n)(*[b.nbytes for b in buffers])
     devs = (_int * n)(*[b.device for b in buffers])
     _check(lib().modgpu_cycle_parts_device(ptrs, sizes, devs, n, as_int32(key)))
+
+
+def cycle_batch_device(ptrs, sizes, key, stream_offs=None, device=-1, stream=None):
+    """Raw device addresses of ONE device, each its own Cycle call (from stream_offs[i] or 0); asynchronous on `stream`.
+    Runs of up to 16 parts share one kernel launch when together they are beyond 256 MiB or small on average."""
+    n = len(ptrs)
+    p = (_vp * n)(*ptrs)
+    z = (_u64 * n)(*sizes)
+    o = (_u64 * n)(*stream_offs) if stream_offs is not None else None
+    _check(lib().modgpu_cycle_batch_device(p, z, o, n, as_int32(key), device, _vp(stream or 0)))
 
 
 def cycle_file(src_path, dst_path, key, stream_off=0, device=-1):

@@ -28,12 +28,40 @@ struct CycleArgs {
                          // timestamps here (wall_clock64, 100 MHz): [blk*32+0] start, [+1+k] end of trip k, [+31] XCC id
 };
 
+// ---- several buffers in ONE launch of the work-queue shape (modgpu_cycle_batch_device) ------------------------------
+// A launch costs ~7 us of pipeline fill, finishing spread and gap to the next one: 5 % of a 411 MB part (BASELINE
+// config 4's part size).  Here the parts' chunks form one index space -- part p owns [start[p], start[p+1]) -- that the
+// same ticket counter hands out, so the fixed cost is paid once per batch.  Every part is its own keystream (its own
+// base states), has its own alignment (lead) and its own ragged edges.
+constexpr int kCycleBatchMax = 16;
+struct CycleBatchPart {
+    uint8_t *body;      // 16-byte aligned start of the part's body
+    uint64_t end;       // lead + body bytes: one past the body's last byte, counted from the chunk origin (body - lead)
+    uint32_t lead;      // body address modulo the chunk size (the cut first chunk, if any, is not in the index space:
+                        // workgroup p does it for part p, with the part's edges)
+    uint32_t base_body; // state of the byte at the chunk origin
+    uint32_t base_head, base_tail;
+    uint32_t head_n, tail_n;
+};
+struct CycleBatchArgs {
+    uint32_t *queue, *queue_done; // as in CycleArgs
+    uint32_t queue_seq, main_groups, helper_below_mhz;
+    uint32_t n_parts;                   // 1 .. kCycleBatchMax
+    uint32_t start[kCycleBatchMax + 1]; // first global chunk index of each part; start[n_parts] = total; unused entries = total
+    CycleBatchPart part[kCycleBatchMax];
+};
+uint32_t modgpu_batch_chunk_bytes();
+uint32_t modgpu_batch_block();
+const char *modgpu_batch_kernel_name();
+hipError_t modgpu_launch_cycle_batch(const CycleBatchArgs &a, uint32_t grid, hipStream_t stream);
+
 // Launch shapes.  A workgroup trip covers `chunk_bytes` contiguous bytes; the grid strides over
 // chunks.  grid * chunk_bytes / 4096 must stay <= 65536 (two-level tile jump table).
 enum CycleVariant : int {
     CYCLE_SMALL = 0, // 256 threads x 1 word : 4 KiB chunks, headers and other small buffers
     CYCLE_LARGE = 1, // 1024 threads x 8 words, software-pipelined, workgroup-synchronous bursts: 128 KiB chunks
     CYCLE_QUEUE = 2, // the same shape, chunks handed out by a ticket counter (needs CycleArgs::queue; < 2^24 chunks)
+    CYCLE_BATCH = 3, // reporting only (modgpu_last_launch): the work-queue shape over several parts, CycleBatchArgs
 };
 constexpr int kCycleVariants = 3;
 uint32_t modgpu_variant_chunk_bytes(int variant);

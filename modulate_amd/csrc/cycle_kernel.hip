@@ -79,7 +79,33 @@ using Large = Shape<8, 1024, 2, 2, AUX_SC1, 3>;
 // chip-wide), 512-thread workgroups and a second chunk of loads in flight lose 1 %; stores sc1+nt gain 0.5-1.8 %
 // over sc1 alone at every size
 using Queue = QueueShape<4, 1024, 2, AUX_SC1 | AUX_NT>;
+// several parts in one launch: the Queue shape over a global chunk index space (CycleBatchArgs)
+struct Batch {
+    static constexpr int U = 4, BLOCK = 1024, ALG = 2, SAUX = AUX_SC1 | AUX_NT;
+    static constexpr uint32_t chunk = (uint32_t)U * BLOCK * lcg::WORD;
+    static_assert(chunk == Queue::chunk, "the host plans a batch with the queue shape's chunk");
+    static void launch(const CycleBatchArgs &a, uint32_t grid, hipStream_t stream)
+    {
+        hipLaunchKernelGGL((modgpu_cycle_batch_kernel<U, BLOCK, ALG, SAUX, 1, AUX_NT>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    }
+    static const char *name()
+    {
+        static char buf[96];
+        static const int n = std::snprintf(buf, sizeof buf, "modgpu_cycle_batch_kernel<%d, %d, %d, %d, 1, %d>", U, BLOCK, ALG, SAUX, (int)AUX_NT);
+        (void)n;
+        return buf;
+    }
+};
 } // namespace
+
+uint32_t modgpu_batch_chunk_bytes() { return Batch::chunk; }
+uint32_t modgpu_batch_block() { return Batch::BLOCK; }
+const char *modgpu_batch_kernel_name() { return Batch::name(); }
+hipError_t modgpu_launch_cycle_batch(const CycleBatchArgs &a, uint32_t grid, hipStream_t stream)
+{
+    Batch::launch(a, grid, stream);
+    return hipGetLastError();
+}
 
 uint32_t modgpu_variant_chunk_bytes(int variant)
 {

@@ -190,18 +190,23 @@ template <int ALG> __device__ __forceinline__ u32x4 cycle_word(u32x4 d, uint32_t
 __device__ __forceinline__ uint8_t cycle_byte(uint8_t d, uint32_t s) { return (uint8_t)~(d ^ (uint8_t)s); }
 
 // < 16 bytes before / after the aligned body, done bytewise by 32 lanes of one workgroup
+__device__ __forceinline__ void cycle_edges(uint8_t *head_ptr, uint32_t head_n, uint32_t base_head, uint8_t *tail_ptr, uint32_t tail_n,
+                                            uint32_t base_tail, uint32_t tid)
+{
+    if (tid < head_n) {
+        uint32_t s = base_head;
+        for (uint32_t j = 0; j < tid; ++j) s = mulmod_canon(s, lcg::A);
+        head_ptr[tid] = cycle_byte(head_ptr[tid], s);
+    } else if (tid >= 16 && tid < 32 && tid - 16 < tail_n) {
+        uint32_t t = tid - 16;
+        uint32_t s = base_tail;
+        for (uint32_t j = 0; j < t; ++j) s = mulmod_canon(s, lcg::A);
+        tail_ptr[t] = cycle_byte(tail_ptr[t], s);
+    }
+}
 __device__ __forceinline__ void cycle_edges(const CycleArgs &a, uint32_t tid)
 {
-    if (tid < a.head_n) {
-        uint32_t s = a.base_head;
-        for (uint32_t j = 0; j < tid; ++j) s = mulmod_canon(s, lcg::A);
-        a.head_ptr[tid] = cycle_byte(a.head_ptr[tid], s);
-    } else if (tid >= 16 && tid < 32 && tid - 16 < a.tail_n) {
-        uint32_t t = tid - 16;
-        uint32_t s = a.base_tail;
-        for (uint32_t j = 0; j < t; ++j) s = mulmod_canon(s, lcg::A);
-        a.tail_ptr[t] = cycle_byte(a.tail_ptr[t], s);
-    }
+    cycle_edges(a.head_ptr, a.head_n, a.base_head, a.tail_ptr, a.tail_n, a.base_tail, tid);
 }
 
 // a^(CHUNK * c) by the three bytes of a chunk index c < 2^24 (queue kernel: a workgroup's next chunk is
@@ -611,6 +616,185 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
             __hip_atomic_store(a.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.queue_done) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // both zeroes have been performed device-wide
+                __hip_atomic_store(a.queue_done, a.queue_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
+// ---- the work-queue kernel over several parts in one launch (CycleBatchArgs, cycle_kernel.h) ------------------------
+// The loop, the bursts, the ticket hand-off, the helper workgroups and the exit are modgpu_cycle_queue_kernel's (the
+// comments there apply); what differs is that a chunk index g is global: it belongs to the part p with
+// start[p] <= g < start[p+1], whose origin, end and base state come from the table in the kernel arguments.  A workgroup's
+// consecutive chunks almost always lie in the same part, so it keeps two cached views -- one for the chunk it is loading,
+// one for the chunk it is finishing -- and walks the table only when a chunk falls outside its view (scalar code, a
+// handful of times per launch).  The part-independent half of a lane's jump (tile and lane powers) is computed once.
+template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int DEPTH = 1, int LAUX = AUX_NT>
+__global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void modgpu_cycle_batch_kernel(CycleBatchArgs a)
+{
+    static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
+    static_assert(DEPTH >= 1 && DEPTH <= 3, "1..3 chunks of loads in flight");
+    constexpr uint32_t CHUNK = (uint32_t)U * BLOCK * lcg::WORD;
+    constexpr uint32_t SUB = BLOCK * lcg::WORD;
+    constexpr int NB = DEPTH + 1;
+    constexpr int PREFIX = DEPTH + 2;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t blk = blockIdx.x;
+    const uint32_t G = gridDim.x;
+    const uint32_t Gm = a.main_groups != 0 && a.main_groups < G ? a.main_groups : G;
+    const uint32_t n_parts = a.n_parts;
+    const uint32_t total = a.start[kCycleBatchMax]; // (unused entries of start[] hold the total as well)
+    __shared__ uint32_t q_next[2];
+    uint32_t trip = 0;
+    const uint32_t voff = tid * lcg::WORD;
+    // a^(4096*(tid/256)) * a^(16*(tid%256)): this lane's word 0 relative to the start of any chunk
+    const uint32_t lane_mul = mulmod_canon(c_tile_lo.v[tid >> 8], c_lane_pow.v[tid & 255]);
+
+    // ragged edges and the cut first chunk of part p: workgroup p (cold code, before the stream starts)
+    for (uint32_t p = blk; p < n_parts; p += G) {
+        const CycleBatchPart &P = a.part[p];
+        const uint64_t body_bytes = P.end - P.lead;
+        if (tid < 32) cycle_edges(P.body - P.head_n, P.head_n, P.base_head, P.body + body_bytes, P.tail_n, P.base_tail, tid);
+        if (P.lead != 0 && body_bytes != 0) {
+            const uint64_t inside = P.end < CHUNK ? body_bytes : CHUNK - P.lead;
+            auto r = __builtin_amdgcn_make_buffer_rsrc(P.body, 0, (int)inside, 0x00020000);
+            uint32_t su = mulmod_canon(P.base_body, lane_mul);
+#pragma unroll 1
+            for (uint32_t u = 0; u < (uint32_t)U; ++u) {
+                const uint32_t o = voff + u * SUB - P.lead; // lanes in front of the body wrap far past num_records: dropped
+                u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, AUX_NT);
+                d = cycle_word<ALG>(d, su);
+                __builtin_amdgcn_raw_buffer_store_b128(d, r, o, 0, SAUX);
+                su = mulmod_canon(su, lcg::kTileLo.v[BLOCK / 256]);
+            }
+        }
+    }
+
+    // the part a global chunk index lies in, as far as the loop needs it
+    struct View {
+        uint8_t *origin;  // body - lead
+        uint64_t end;
+        uint32_t base;    // state at the origin
+        uint32_t lo, hi;  // global indices [lo, hi) map to local chunks first + (g - lo)
+        uint32_t first;   // 1 if the part's chunk 0 is the cut one (done above)
+    };
+    auto locate = [&](uint32_t g, View &v) {
+        if (g - v.lo < v.hi - v.lo) return; // lo <= g < hi
+        uint32_t p = 0;
+#pragma unroll 1
+        for (uint32_t i = 1; i < n_parts; ++i) p += g >= a.start[i] ? 1u : 0u; // (empty parts share their start with the next one: skipped)
+        const CycleBatchPart &P = a.part[p];
+        v.origin = P.body - P.lead;
+        v.end = P.end;
+        v.base = P.base_body;
+        v.first = P.lead != 0 ? 1u : 0u;
+        v.lo = a.start[p];
+        v.hi = a.start[p + 1];
+    };
+    auto rsrc_at = [&](uint32_t g, const View &v) {
+        const uint64_t o = (uint64_t)(v.first + (g - v.lo)) * CHUNK;
+        const uint64_t left = g < v.hi && o < v.end ? v.end - o : 0; // past the part (only ever: past the last part): zero-size descriptor
+        return __builtin_amdgcn_make_buffer_rsrc(v.origin + o, 0, (int)(left < CHUNK ? left : CHUNK), 0x00020000);
+    };
+    auto states = [&](uint32_t g, const View &v, uint32_t(&s)[U]) {
+        const uint32_t c = v.first + (g - v.lo);
+        uint32_t p = mulmod_canon(c_chunk_pow0<CHUNK>.v[c & 255], c_chunk_pow1<CHUNK>.v[(c >> 8) & 255]);
+        p = mulmod_canon(p, c_chunk_pow2<CHUNK>.v[(c >> 16) & 255]);
+        s[0] = mulmod_canon(mulmod_canon(v.base, p), lane_mul);
+#pragma unroll
+        for (int u = 1; u < U; ++u) s[u] = mulmod_canon(s[u - 1], lcg::kTileLo.v[BLOCK / 256]);
+    };
+    View vl{nullptr, 0, 1, 0, 0, 0}, vs{nullptr, 0, 1, 0, 0, 0}; // load side, store side
+    auto load = [&](u32x4(&d)[U], uint32_t g) {
+        locate(g, vl);
+        auto r = rsrc_at(g, vl);
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, LAUX);
+    };
+    uint32_t pending = 0;
+    const uint32_t q_next_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&q_next[0];
+    const uint32_t one = 1u;
+    auto process_store = [&](u32x4(&d)[U], uint32_t g, bool publish) {
+        locate(g, vs);
+        auto r = rsrc_at(g, vs);
+        uint32_t s[U];
+        states(g, vs, s);
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = cycle_word<ALG>(d[u], s[u]);
+        if (publish && tid == 0)
+            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(q_next_lds + 4u * (trip & 1u)), "v"(pending) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) pending = __hip_atomic_fetch_add(a.queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
+        ++trip;
+    };
+    auto take_published = [&]() {
+        uint32_t t;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(q_next_lds + 4u * ((trip - 1u) & 1u)) : "memory");
+        return (uint32_t)PREFIX * Gm + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    };
+
+    uint32_t cq[NB];
+    uint32_t last_static;
+    bool active = true;
+    if (blk < Gm) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) cq[i] = blk + (uint32_t)i * Gm;
+        last_static = blk + (uint32_t)NB * Gm;
+    } else { // a helper workgroup: looks at the shader clock once, joins (tickets only) while it is low
+        if (tid == 0) {
+            const uint64_t t0 = wall_clock64(), c0 = clock64();
+            uint64_t t1;
+            do {
+                __builtin_amdgcn_s_sleep(4);
+                t1 = wall_clock64();
+            } while (t1 - t0 < 200);
+            const uint64_t mhz = ((clock64() - c0) * 100) / (t1 - t0);
+            uint32_t t = 0xFFFFFFFFu;
+            if (mhz < a.helper_below_mhz) t = __hip_atomic_fetch_add(a.queue, (uint32_t)PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q_next[0] = t;
+        }
+        __syncthreads();
+        const uint32_t t = q_next[0];
+        __syncthreads();
+        active = t != 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) cq[i] = (uint32_t)PREFIX * Gm + t + (uint32_t)i;
+        last_static = (uint32_t)PREFIX * Gm + t + (uint32_t)NB;
+    }
+    if (active && cq[0] < total) {
+        u32x4 d[NB][U];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) load(d[i], cq[i]);
+        bool publish = false;
+        bool finished = false;
+        while (!finished) {
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                __builtin_amdgcn_s_barrier();
+                load(d[(p + DEPTH) % NB], cq[DEPTH]);
+                __builtin_amdgcn_sched_barrier(0);
+                process_store(d[p], cq[0], publish);
+#pragma unroll
+                for (int i = 0; i < DEPTH; ++i) cq[i] = cq[i + 1];
+                cq[DEPTH] = publish ? take_published() : last_static;
+                publish = true;
+                if (cq[0] >= total) {
+                    finished = true;
+                    break;
+                }
+            }
+        }
+    }
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(a.queue + 1, 1u) == G - 1) {
+            __hip_atomic_store(a.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.queue_done) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(a.queue_done, a.queue_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }

@@ -60,5 +60,44 @@ hipError_t modgpu_launch_cycle(const CycleArgs &a, int variant, uint32_t, hipStr
     return hipSuccess;
 }
 
+// several parts in one launch: the same, part by part, from the batch plan (start[] must tile the chunk index space)
+namespace {
+std::atomic<unsigned long long> g_batch_launches{0}, g_batch_plan_errors{0};
+void run_batch(void *arg)
+{
+    CycleBatchArgs *b = static_cast<CycleBatchArgs *>(arg);
+    uint32_t expect = 0;
+    if (!std::atomic_ref<uint32_t>(b->queue[0]).compare_exchange_strong(expect, 1u)) g_collisions.fetch_add(1);
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+    const uint64_t chunk = modgpu_batch_chunk_bytes();
+    uint64_t total = 0;
+    for (uint32_t p = 0; p < b->n_parts; ++p) {
+        const CycleBatchPart &P = b->part[p];
+        const uint64_t body_bytes = P.end - P.lead, n_chunks = (P.end + chunk - 1) / chunk, first = P.lead != 0 ? 1 : 0;
+        if (b->start[p] != total || (reinterpret_cast<uintptr_t>(P.body) & (chunk - 1)) != P.lead) g_batch_plan_errors.fetch_add(1);
+        total += n_chunks > first ? n_chunks - first : 0;
+        span(P.body - P.head_n, P.head_n, P.base_head);
+        span(P.body, body_bytes, lcg::mulmod(P.base_body, lcg::powmod(lcg::A, P.lead)));
+        span(P.body + body_bytes, P.tail_n, P.base_tail);
+    }
+    for (uint32_t p = b->n_parts; p <= (uint32_t)kCycleBatchMax; ++p)
+        if (b->start[p] != total) g_batch_plan_errors.fetch_add(1);
+    std::atomic_ref<uint32_t>(b->queue[0]).store(0u);
+    if (b->queue_done) std::atomic_ref<uint32_t>(*b->queue_done).store(b->queue_seq, std::memory_order_release);
+    g_batch_launches.fetch_add(1);
+    delete b;
+}
+} // namespace
+uint32_t modgpu_batch_chunk_bytes() { return 65536u; }
+uint32_t modgpu_batch_block() { return 1024u; }
+const char *modgpu_batch_kernel_name() { return "shim batch"; }
+hipError_t modgpu_launch_cycle_batch(const CycleBatchArgs &a, uint32_t, hipStream_t stream)
+{
+    shim::enqueue(stream, run_batch, new CycleBatchArgs(a));
+    return hipSuccess;
+}
+extern "C" unsigned long long modgpu_shim_batch_launches(void) { return g_batch_launches.load(); }
+extern "C" unsigned long long modgpu_shim_batch_plan_errors(void) { return g_batch_plan_errors.load(); }
+
 extern "C" unsigned long long modgpu_shim_pair_collisions(void) { return g_collisions.load(); }
 extern "C" unsigned long long modgpu_shim_launches(int variant) { return variant >= 0 && variant < kCycleVariants ? g_launches[variant].load() : 0; }

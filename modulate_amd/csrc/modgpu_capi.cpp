@@ -369,6 +369,14 @@ int helper_mode() { return g_helper_mode.load(std::memory_order_relaxed); }
 constexpr int helper_mode() { return 0; }
 #endif
 
+#ifdef MODGPU_TESTING_HOOKS
+std::atomic<int> g_batch_mode{0}; // modgpu_debug_set_batch: 0 by size, 1 every group of >= 2 parts, 2 never
+int batch_mode() { return g_batch_mode.load(std::memory_order_relaxed); }
+#else
+constexpr int batch_mode() { return 0; }
+#endif
+std::atomic<uint64_t> g_batch_launches{0}, g_batch_parts{0};
+
 constexpr uint32_t kSmallGridMax = 16384u;   // 4 KiB chunks: grid * 1 tile <= 65536
 // Hand-over between the two shapes, measured warm and cold (profiles/r01_tune_cycle_sizes*.txt):
 // up to 256 MiB the one-shot 4 KiB-chunk grid wins (launch cost ~3 us vs ~9 us, and the buffer fits
@@ -381,6 +389,21 @@ constexpr uint64_t kLargeMin = (256ull << 20) + 1;
 // dozen workgroups of the one-word shape; more only adds contention (profiles/r02_sweep_pinned_routes.txt:
 // 4 KiB chunks, grid <= 256: 50 GB/s of payload at 64 MiB .. 4 GiB; uncapped 46; the streaming shape 41-46).
 constexpr uint32_t kPcieGridMax = 256u;
+
+// Workgroups of a work-queue launch over `chunks` chunks on a device of `cus` CUs: most main workgroups, and helpers.
+void queue_grid(uint64_t chunks, uint64_t cus, uint64_t *main_cap, uint64_t *helpers)
+{
+    const uint32_t grid_cap = forced_grid_cap();
+    uint64_t cap = std::max<uint64_t>(1, cus * 25 / 32);
+    const bool capped = grid_cap >= 1 && grid_cap < cus; // (testing flavour: a forced grid)
+    if (capped && grid_cap < cap) cap = grid_cap;
+    // (a launch of a few trips is over before a helper has looked at the clock; a forced grid gets helpers only when the
+    //  tests force them to join, in the product's proportion)
+    *helpers = 0;
+    if (helper_mode() == 1) *helpers = capped ? std::max<uint64_t>(1, cap * 7 / 25) : cus - cap;
+    else if (helper_mode() == 0 && !capped && chunks >= 4 * cus) *helpers = cus - cap;
+    *main_cap = cap;
+}
 
 Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off, bool over_pcie, hipStream_t stream)
 {
@@ -437,14 +460,7 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
     uint64_t helpers = 0;
     const uint32_t grid_cap = forced_grid_cap();
     if (p.variant == CYCLE_QUEUE) {
-        const uint64_t cus = cap;
-        cap = std::max<uint64_t>(1, cus * 25 / 32);
-        const bool capped = grid_cap >= 1 && grid_cap < cus; // (testing flavour: a forced grid)
-        if (capped && grid_cap < cap) cap = grid_cap;
-        // (a launch of a few trips is over before a helper has looked at the clock; a forced grid gets helpers only when the
-        //  tests force them to join, in the product's proportion)
-        if (helper_mode() == 1) helpers = capped ? std::max<uint64_t>(1, cap * 7 / 25) : cus - cap;
-        else if (helper_mode() == 0 && !capped && chunks >= 4 * cus) helpers = cus - cap;
+        queue_grid(chunks, cap, &cap, &helpers);
     } else if (grid_cap >= 1 && grid_cap < cap) {
         cap = grid_cap;
     }
@@ -480,6 +496,100 @@ int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_of
     g_stats.gpu_launches.fetch_add(1, std::memory_order_relaxed);
     t_last_launch = {modgpu_variant_kernel_name(p.variant), p.variant, p.grid, modgpu_variant_block(p.variant),
                      modgpu_variant_chunk_bytes(p.variant), n, p.variant == CYCLE_QUEUE ? p.args.main_groups : p.grid};
+    return MODGPU_OK;
+}
+
+namespace {
+// One launch of the work-queue shape over parts[0..n) (2..kCycleBatchMax non-empty buffers of the current device).
+// Returns MODGPU_OK, an error, or 1: not possible right now (no ticket pair free, a part beyond the jump tables) --
+// the caller launches the parts one by one.
+int launch_batch(void *const *bufs, const uint64_t *sizes, const uint64_t *offs, int n, uint32_t key_res, hipStream_t stream)
+{
+    CycleBatchArgs a{};
+    const uint64_t chunk = modgpu_batch_chunk_bytes();
+    uint64_t total = 0, bytes = 0;
+    for (int k = 0; k < n; ++k) {
+        CycleBatchPart &P = a.part[k];
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(bufs[k]);
+        const uint64_t head = std::min<uint64_t>(sizes[k], (16 - (addr & 15)) & 15);
+        const uint64_t words = (sizes[k] - head) / 16;
+        const uint64_t o = (offs ? offs[k] : 0) % lcg::PERIOD;
+        P.body = static_cast<uint8_t *>(bufs[k]) + head;
+        P.head_n = (uint32_t)head;
+        P.tail_n = (uint32_t)(sizes[k] - head - words * 16);
+        P.lead = (uint32_t)(reinterpret_cast<uintptr_t>(P.body) & (chunk - 1));
+        P.end = P.lead + words * 16;
+        P.base_head = lcg::state_residue(key_res, o);
+        P.base_body = lcg::mulmod(lcg::state_residue(key_res, o + head), lcg::powmod(lcg::A, lcg::PERIOD - P.lead % lcg::PERIOD));
+        P.base_tail = lcg::state_residue(key_res, o + head + (words * 16) % lcg::PERIOD);
+        const uint64_t n_chunks = (P.end + chunk - 1) / chunk, first = P.lead != 0 ? 1 : 0;
+        if (n_chunks >= (1ull << 24)) return 1; // the kernel's chunk jump tables are three bytes wide
+        a.start[k] = (uint32_t)total;
+        total += n_chunks > first ? n_chunks - first : 0; // the cut first chunk is workgroup k's, outside the index space
+        bytes += sizes[k];
+    }
+    for (int k = n; k <= kCycleBatchMax; ++k) a.start[k] = (uint32_t)total;
+    a.n_parts = (uint32_t)n;
+    const QueuePair q = queue_pair(stream);
+    if (!q.pair) return 1;
+    a.queue = q.pair;
+    a.queue_done = q.done;
+    a.queue_seq = q.seq;
+    uint64_t cap = 0, helpers = 0;
+    queue_grid(total, large_grid(), &cap, &helpers);
+    const uint64_t main_groups = std::max<uint64_t>(1, std::min<uint64_t>(total, cap));
+    a.main_groups = (uint32_t)main_groups;
+    a.helper_below_mhz = helper_mode() == 1 ? 0xFFFFFFFFu : helper_below_mhz();
+    const uint32_t grid = (uint32_t)(main_groups + helpers);
+    hipError_t e = modgpu_launch_cycle_batch(a, grid, stream);
+    if (e != hipSuccess) {
+        queue_pair_unused(q);
+        return fail_hip(e, "cycle batch kernel launch");
+    }
+    g_stats.gpu_launches.fetch_add(1, std::memory_order_relaxed);
+    g_batch_launches.fetch_add(1, std::memory_order_relaxed);
+    g_batch_parts.fetch_add((uint64_t)n, std::memory_order_relaxed);
+    t_last_launch = {modgpu_batch_kernel_name(), CYCLE_BATCH, grid, modgpu_batch_block(), (uint32_t)chunk, bytes, (uint32_t)main_groups};
+    return MODGPU_OK;
+}
+} // namespace
+
+// n_parts buffers resident on the CURRENT device, each its own Cycle call (keystream from offs[i], or 0), asynchronous on
+// `stream`.  Runs of up to kCycleBatchMax non-empty parts share one launch when that pays (profiles/r03_parts_batched.txt,
+// one launch per part against one per run, 2..16 parts of 64 KiB..4 GiB): together beyond the small shape's range -- a
+// launch's ~7 us of fixed cost is 5 % of a 411 MB part, and parts of 50-100 MB gain 16-30 % -- or small on average, where
+// the per-launch cost is most of the time (16 x 1 MiB: 3x).  Only a few mid-sized parts that together fit the Infinity
+// Cache (2 x 64 MiB: -12 %, 4 x 32 MiB: even) are better off with the one-shot small launches.  Everything else is
+// launched part by part.
+constexpr uint64_t kBatchSmallMean = 24ull << 20;
+int cycle_batch_impl(void *const *bufs, const uint64_t *sizes, const uint64_t *offs, int n_parts, int32_t key, hipStream_t stream)
+{
+    for (int i = 0; i < n_parts; ++i)
+        if (sizes[i] && !bufs[i]) return fail(MODGPU_ERR_INVALID, "null device buffer");
+    const uint32_t key_res = lcg::key_residue(key);
+    if (key_res == 0) return MODGPU_OK;
+    int i = 0;
+    while (i < n_parts) {
+        void *gb[kCycleBatchMax];
+        uint64_t gs[kCycleBatchMax], go[kCycleBatchMax], bytes = 0;
+        int g = 0;
+        for (; i < n_parts && g < kCycleBatchMax; ++i) {
+            if (!sizes[i]) continue;
+            gb[g] = bufs[i];
+            gs[g] = sizes[i];
+            go[g] = offs ? offs[i] : 0;
+            bytes += sizes[i];
+            ++g;
+        }
+        int rc = 1;
+        if (g >= 2 && batch_mode() != 2 && (batch_mode() == 1 || bytes >= kLargeMin || bytes <= kBatchSmallMean * (uint64_t)g))
+            rc = launch_batch(gb, gs, go, g, key_res, stream);
+        if (rc == 1) {
+            rc = MODGPU_OK;
+            for (int k = 0; k < g && rc == MODGPU_OK; ++k) rc = cycle_device_impl(gb[k], gs[k], key, go[k], stream);
+        }
+        if (rc != MODGPU_OK) return rc;
+    }
     return MODGPU_OK;
 }
 
@@ -606,6 +716,17 @@ int modgpu_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_
     });
 }
 
+int modgpu_cycle_batch_device(void *const *dev_parts, const uint64_t *sizes, const uint64_t *stream_offs, int n_parts, int32_t key,
+                              int device, void *hip_stream)
+{
+    return guarded([&]() -> int {
+        if (n_parts < 0 || (n_parts > 0 && (!dev_parts || !sizes))) return fail(MODGPU_ERR_INVALID, "bad part list");
+        DeviceScope scope(device);
+        if (scope.rc) return scope.rc;
+        return cycle_batch_impl(dev_parts, sizes, stream_offs, n_parts, key, static_cast<hipStream_t>(hip_stream));
+    });
+}
+
 int modgpu_cycle_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, int device)
 {
     return guarded([&]() -> int { return cycle_host_impl(host_buf, n, key, stream_off, device, nullptr); });
@@ -717,15 +838,31 @@ int modgpu_cycle_parts_device(void *const *dev_parts, const uint64_t *sizes, con
         if (n_parts < 0 || (n_parts > 0 && (!dev_parts || !sizes || !devices))) return fail(MODGPU_ERR_INVALID, "bad part list");
         DeviceScope keep(-1, /*always_save=*/true); // this thread visits every part's GPU and leaves as it came
         int rc = MODGPU_OK;
-        int launched = 0;
-        for (; launched < n_parts && rc == MODGPU_OK; ++launched) { // every part its own Cycle from stream offset 0
-            if (devices[launched] < 0) rc = fail(MODGPU_ERR_INVALID, "a part needs an explicit device");
-            if (rc == MODGPU_OK) rc = select_device(devices[launched]);
-            if (rc == MODGPU_OK) rc = cycle_device_impl(dev_parts[launched], sizes[launched], key, 0, nullptr);
+        for (int i = 0; i < n_parts && rc == MODGPU_OK; ++i)
+            if (devices[i] < 0) rc = fail(MODGPU_ERR_INVALID, "a part needs an explicit device");
+        if (rc != MODGPU_OK) return rc;
+        // every part its own Cycle from stream offset 0; the parts of one device go to it together (cycle_batch_impl)
+        std::vector<char> taken((size_t)n_parts, 0);
+        std::vector<int> started;
+        for (int i = 0; i < n_parts && rc == MODGPU_OK; ++i) {
+            if (taken[(size_t)i]) continue;
+            std::vector<void *> bufs;
+            std::vector<uint64_t> lens;
+            for (int j = i; j < n_parts; ++j)
+                if (devices[j] == devices[i]) {
+                    taken[(size_t)j] = 1;
+                    bufs.push_back(dev_parts[j]);
+                    lens.push_back(sizes[j]);
+                }
+            rc = select_device(devices[i]);
+            if (rc == MODGPU_OK) {
+                started.push_back(devices[i]);
+                rc = cycle_batch_impl(bufs.data(), lens.data(), nullptr, (int)bufs.size(), key, nullptr);
+            }
         }
         const std::string why = t_err;
-        for (int i = 0; i < launched; ++i) { // wait for what was started, also on the error path
-            if (devices[i] < 0 || select_device(devices[i]) != MODGPU_OK) continue;
+        for (int d : started) { // wait for what was started, also on the error path
+            if (select_device(d) != MODGPU_OK) continue;
             hipError_t e = hipStreamSynchronize(nullptr);
             if (e != hipSuccess && rc == MODGPU_OK) rc = fail_hip(e, "hipStreamSynchronize");
         }
@@ -1070,12 +1207,14 @@ int modgpu_numa_probe(const char *sysfs_root, const char *bdf, int *node, int *c
     return n;
 }
 
-void modgpu_queue_stats(uint64_t out[4])
+void modgpu_queue_stats(uint64_t out[6])
 {
     out[0] = g_queue_eager.load();
     out[1] = g_queue_busy.load();
     out[2] = g_queue_graph.load();
     out[3] = g_queue_graph_full.load();
+    out[4] = g_batch_launches.load();
+    out[5] = g_batch_parts.load();
 }
 
 const char *modgpu_kernel_source_hash(void) { return MODGPU_KERNEL_SOURCE_HASH; }
@@ -1100,6 +1239,8 @@ void modgpu_debug_set_pinned_mode(int mode) { g_pinned_mode.store(mode, std::mem
 void modgpu_debug_set_staged_mode(int mode) { g_staged_mode.store(mode, std::memory_order_relaxed); }
 
 void modgpu_debug_set_helpers(int mode) { g_helper_mode.store(mode >= 0 && mode <= 2 ? mode : 0, std::memory_order_relaxed); }
+
+void modgpu_debug_set_batch(int mode) { g_batch_mode.store(mode >= 0 && mode <= 2 ? mode : 0, std::memory_order_relaxed); }
 
 void modgpu_debug_set_queue_ring(uint32_t lines)
 {

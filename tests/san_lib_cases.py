@@ -26,6 +26,8 @@ def lib():
     assert M.testing_hooks() and M.device_count() == 8, "expects the shim build with MODGPU_SHIM_DEVICES=8"
     L.modgpu_shim_pair_collisions.restype = ctypes.c_ulonglong
     L.modgpu_shim_launches.restype = ctypes.c_ulonglong
+    L.modgpu_shim_batch_launches.restype = ctypes.c_ulonglong
+    L.modgpu_shim_batch_plan_errors.restype = ctypes.c_ulonglong
     return L
 
 
@@ -40,6 +42,7 @@ def hooks(lib):
             M.debug_set_staged_mode(0)
             M.debug_set_queue_ring(0)
             M.debug_set_helpers(0)
+            M.debug_set_batch(0)
             M.debug_inject_failures(0)
 
 
@@ -68,6 +71,84 @@ def test_launch_plan_sizes_alignments_shapes(hooks):
                 O.cycle_at(w[64 + al:64 + al + n], key, so)
                 assert np.array_equal(d.download(n + 128), w), (shape, n, al)
     d.free()
+
+
+def test_batch_plan_of_several_parts_in_one_launch(hooks, lib):
+    """modgpu_cycle_batch_device / _parts_device: the plan of a launch that carries several parts -- every part its own
+    split, lead, base states and slice of the chunk index space (the shim checks start[] tiles it) -- for ragged sizes
+    (empty, edge-only, inside the cut first chunk, chunk multiples), every alignment class, own stream offsets, more
+    than sixteen parts (two launches), and the one-launch-per-part fallbacks (mode 2; ring busy)."""
+    rng = np.random.default_rng(7)
+    sizes = [0, 1, 15, 16, 17, 31, 4096, 65535, 65536, 65537, 131072, 200_003, 3, 70_000, 0, 65536 * 3 + 9, 12, 40_000, 65536 * 2]
+    slack = 96
+    cap = sum(sizes) + slack * len(sizes) + 65536
+    d = M.DeviceBuffer(cap)
+    for mode, ring in ((1, 0), (2, 0), (0, 0)):
+        M.debug_set_batch(mode)
+        before, launches0 = M.queue_stats(), lib.modgpu_shim_batch_launches()
+        whole = rng.integers(0, 256, size=cap, dtype=np.uint8)
+        d.upload(whole)
+        w = whole.copy()
+        ptrs, offs, pos = [], [], 13
+        for i, n in enumerate(sizes):
+            pos += (i * 7) % 16                      # every alignment class against the 16-byte word
+            ptrs.append(d.ptr + pos)
+            offs.append([0, O.PERIOD - 5, (1 << 33) + i][i % 3])
+            O.cycle_at(w[pos:pos + n], 0xC64EED30, offs[-1])
+            pos += n + slack
+        M.cycle_batch_device(ptrs, sizes, 0xC64EED30, stream_offs=offs, device=d.device)
+        d.sync()
+        assert np.array_equal(d.download(cap), w), mode
+        after = M.queue_stats()
+        carried = after["batch_parts"] - before["batch_parts"]
+        if mode != 2:  # 17 non-empty parts: sixteen in one launch; the seventeenth is alone in its run: its own launch
+            assert after["batch_launches"] - before["batch_launches"] == 1 and carried == 16, after  # (mode 0: small on average)
+            assert lib.modgpu_shim_batch_launches() - launches0 == 1
+            assert M.last_launch()["variant"] != 3
+        else:
+            assert carried == 0
+    # the shipped rule says no to a few mid-sized parts that together fit the Infinity Cache
+    M.debug_set_batch(0)
+    two = [M.DeviceBuffer(26 << 20, device=1) for _ in range(2)]
+    before = M.queue_stats()
+    M.cycle_batch_device([b.ptr for b in two], [b.nbytes for b in two], 0, device=1)   # (key 0: identity, nothing launched)
+    M.cycle_batch_device([b.ptr for b in two], [64, 64], 5, device=1)
+    M.cycle_batch_device([b.ptr for b in two], [b.nbytes for b in two], 5, device=1)
+    two[0].sync()
+    after = M.queue_stats()
+    assert after["batch_launches"] - before["batch_launches"] == 1 and after["batch_parts"] - before["batch_parts"] == 2
+    for b in two:
+        b.free()
+    # without stream offsets (every part from 0), through the per-device grouping of modgpu_cycle_parts_device
+    M.debug_set_batch(1)
+    bufs = [M.DeviceBuffer(n, device=dev) for n, dev in ((70_001, 2), (5, 2), (300_000, 5), (65536, 2), (99_999, 5))]
+    pts = [rng.integers(0, 256, size=b.nbytes, dtype=np.uint8) for b in bufs]
+    for b, pt in zip(bufs, pts):
+        b.upload(pt)
+    before = M.queue_stats()
+    M.cycle_parts_device(bufs, 0x90CFC0AB)
+    after = M.queue_stats()
+    assert after["batch_launches"] - before["batch_launches"] == 2 and after["batch_parts"] - before["batch_parts"] == 5
+    for b, pt in zip(bufs, pts):
+        assert np.array_equal(b.download(b.nbytes), want(pt, 0x90CFC0AB))
+    # ring of one line, held by a launch in flight on another stream: the batch falls back to one launch per part
+    M.debug_set_queue_ring(1)
+    M.debug_set_launch("queue", 0)
+    big = M.DeviceBuffer(1 << 20, device=2)                # (the ring is per device)
+    big.upload(np.zeros(1 << 20, np.uint8))
+    before = M.queue_stats()
+    big.cycle(1)                                       # takes the only line (the shim's launches last >= 200 us)
+    M.cycle_batch_device([b.ptr for b in bufs[:2]], [b.nbytes for b in bufs[:2]], 0x90CFC0AB, device=2)
+    for b in bufs[:2]:
+        b.sync()
+    big.sync()
+    after = M.queue_stats()
+    assert after["batch_launches"] == before["batch_launches"] and after["busy_fallbacks"] > before["busy_fallbacks"]
+    for b, pt in zip(bufs[:2], pts[:2]):
+        assert np.array_equal(b.download(b.nbytes), pt)  # cycled twice: back to the plaintext
+    assert lib.modgpu_shim_batch_plan_errors() == 0 and lib.modgpu_shim_pair_collisions() == 0
+    for b in bufs + [big, d]:
+        b.free()
 
 
 def test_staged_pipelines_and_routes(hooks):

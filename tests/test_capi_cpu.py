@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(modgpu):
     assert modgpu.active_flavour() == "shipped" and not modgpu.testing_hooks()
     for name in list(modgpu.EXPORTS) + list(modgpu.TESTING_EXPORTS):
         assert getattr(L, name) is not None
-    assert L.modgpu_abi_version() == 4
+    assert L.modgpu_abi_version() == 5
 
     def exported(path):
         out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout

@@ -46,6 +46,7 @@ def gpu_t(gpu):
             gpu.debug_set_staged_mode(0)
             gpu.debug_set_queue_ring(0)
             gpu.debug_set_helpers(0)
+            gpu.debug_set_batch(0)
             gpu.debug_inject_failures(0)
     assert gpu.active_flavour() == "shipped"
 
@@ -485,6 +486,88 @@ def test_helper_workgroups_of_the_queue_shape(gpu_t, oracle, mode):
                 oracle.cycle_at(w[base - lo:base - lo + n], 0xC64EED30, n)
                 assert np.array_equal(d.download(n + 128, offset=lo), w), (grid, n, base)
         d.free()
+
+
+@pytest.mark.parametrize("helpers", [2, 1], ids=["no_helpers", "helpers_join"])
+def test_several_parts_in_one_launch_ragged(gpu_t, oracle, helpers):
+    """modgpu_cycle_batch_device, forced to batch whatever the sizes: parts that are empty, edge-only, inside the cut first
+    chunk, exact chunk multiples, a few chunks long; every alignment class; each with its own stream offset; 17 non-empty
+    parts (one launch of sixteen + the last one alone); full grid and forced grids from 1 workgroup up (fewer workgroups
+    than parts included: the edges and cut first chunks are dealt round-robin).  The whole arena is compared."""
+    gpu = gpu_t
+    gpu.debug_set_batch(1)
+    gpu.debug_set_helpers(helpers)
+    rng = np.random.default_rng(11 + helpers)
+    sizes = [0, 1, 15, 16, 17, 31, 4096, 65535, 65536, 65537, 131072, 200_003, 3, 70_000, 0, 65536 * 3 + 9, 12, 40_000, 65536 * 21 + 1]
+    slack = 96
+    cap = sum(sizes) + slack * len(sizes) + 65536
+    d = gpu.DeviceBuffer(cap)
+    for grid in (0, 1, 3, 7, 64):
+        gpu.debug_set_launch(None, grid)
+        whole = rng.integers(0, 256, size=cap, dtype=np.uint8)
+        d.upload(whole)
+        w = whole.copy()
+        ptrs, offs, pos = [], [], int(rng.integers(0, 64))
+        for i, n in enumerate(sizes):
+            pos += (i * 7 + grid) % 16
+            ptrs.append(d.ptr + pos)
+            offs.append([0, oracle.PERIOD - 5, (1 << 33) + i, n][i % 4])
+            oracle.cycle_at(w[pos:pos + n], 0xC64EED30, offs[-1])
+            pos += n + slack
+        before = gpu.queue_stats()
+        gpu.cycle_batch_device(ptrs, sizes, 0xC64EED30, stream_offs=offs, device=d.device)
+        d.sync()
+        after = gpu.queue_stats()
+        assert after["batch_launches"] - before["batch_launches"] == 1 and after["batch_parts"] - before["batch_parts"] == 16
+        assert np.array_equal(d.download(cap), w), grid
+        # the same parts again, from offset 0 each and all in launches of their own (mode 2), then undone by a batch
+        gpu.debug_set_batch(2)
+        gpu.cycle_batch_device(ptrs, sizes, 0x90CFC0AB, device=d.device)
+        gpu.debug_set_batch(1)
+        gpu.cycle_batch_device(ptrs[:16], sizes[:16], 0x90CFC0AB, device=d.device)
+        info = gpu.last_launch()
+        assert info["variant"] == 3 and info["kernel"].startswith("modgpu_cycle_batch_kernel<") and info["bytes"] == sum(sizes[:16]), info
+        gpu.cycle_batch_device(ptrs[16:], sizes[16:], 0x90CFC0AB, device=d.device)
+        d.sync()
+        assert np.array_equal(d.download(cap), w), ("involution across the two routes", grid)
+    d.free()
+
+
+def test_several_parts_in_one_launch_at_part_sizes(gpu, oracle):
+    """The shipped decision on the shipped library: five resident parts of 50-90 MB (beyond 256 MiB together) take ONE launch,
+    each with its own keystream from 0 -- through modgpu_cycle_parts_device, whole parts compared with the oracle, then a
+    second pass restores them; two parts under 256 MiB together take a launch each."""
+    rng = np.random.default_rng(3)
+    sizes = [90_000_001, 50_331_648, 77_777_777, 65_536_000, 60_000_013]
+    bufs = [gpu.DeviceBuffer(n + 32) for n in sizes]
+    pts = [oracle.splitmix_bytes(n + 32, 900 + i) for i, n in enumerate(sizes)]
+    for b, pt in zip(bufs, pts):
+        b.upload(pt)
+    base = [0, 4, 0, 9, 16]  # the reference's callers pass buf+4
+    before = gpu.queue_stats()
+    gpu.cycle_batch_device([b.ptr + o for b, o in zip(bufs, base)], sizes, gpu.KEY_PS4, device=0)
+    bufs[0].sync()
+    info = gpu.last_launch()
+    assert info["variant"] == 3 and info["grid"] == 256 and info["main_groups"] == 200 and info["bytes"] == sum(sizes), info
+    after = gpu.queue_stats()
+    assert after["batch_launches"] - before["batch_launches"] == 1 and after["batch_parts"] - before["batch_parts"] == 5
+    for b, pt, o, n in zip(bufs, pts, base, sizes):
+        w = pt.copy()
+        oracle.cycle(w[o:o + n], oracle.KEY_PS4)
+        assert np.array_equal(b.download(), w), n
+    gpu.cycle_batch_device([b.ptr + o for b, o in zip(bufs, base)], sizes, gpu.KEY_PS4, device=0)
+    bufs[0].sync()
+    for b, pt in zip(bufs, pts):
+        assert np.array_equal(b.download(), pt)
+    gpu.cycle_batch_device([bufs[1].ptr, bufs[4].ptr], [sizes[1], sizes[4]], gpu.KEY_PS3, device=0)  # 110 MB in all
+    bufs[0].sync()
+    assert gpu.queue_stats()["batch_launches"] == after["batch_launches"] + 1 and gpu.last_launch()["variant"] == 0
+    for i in (1, 4):
+        w = pts[i].copy()
+        oracle.cycle(w[:sizes[i]], oracle.KEY_PS3)
+        assert np.array_equal(bufs[i].download(), w)
+    for b in bufs:
+        b.free()
 
 
 @pytest.mark.parametrize("ring", [1, 2, 0], ids=["ring1", "ring2", "ring4096"])
