@@ -26,6 +26,8 @@
 //   large   the same bursts with the static chunk map (b, b+G, ...), 128 KiB chunks, one workgroup per CU: what a
 //           launch takes when no ticket pair is free, or beyond 2^24 chunks.
 //   small   256 threads x one word, no pipeline: headers ... 256 MiB, and page-locked host memory across PCIe.
+// and the queue shape once more over SEVERAL buffers in one launch (modgpu_cycle_batch_kernel, CycleBatchArgs): an
+// archive's parts resident on one GPU share the launch's fixed cost; the part table travels in the kernel arguments.
 // DESIGN.md 3-4 has the measurements behind each of these choices.
 #include <hip/hip_runtime.h>
 #include <cstdint>

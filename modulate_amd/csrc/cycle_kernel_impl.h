@@ -402,6 +402,50 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
     }
 }
 
+// ---- pieces shared by the two work-queue kernels (one buffer / several parts) ------------------------
+namespace {
+// A HELPER workgroup's decision, made once when it starts (see modgpu_cycle_queue_kernel): lane 0 measures the shader
+// clock -- s_memtime ticks per 2 us of the constant 100 MHz counter -- and, while it is below `below_mhz`, draws the
+// workgroup's first PREFIX chunks from the ticket counter.  Returns the first ticket to every lane, 0xFFFFFFFF = leave.
+// `mailbox` is the workgroup's LDS ticket word 0, free again when this returns.
+template <int PREFIX> __device__ __forceinline__ uint32_t helper_first_ticket(uint32_t *queue, uint32_t below_mhz, uint32_t *mailbox)
+{
+    if (threadIdx.x == 0) {
+        const uint64_t t0 = wall_clock64(), c0 = clock64();
+        uint64_t t1;
+        do {
+            __builtin_amdgcn_s_sleep(4);
+            t1 = wall_clock64();
+        } while (t1 - t0 < 200);
+        const uint64_t mhz = ((clock64() - c0) * 100) / (t1 - t0);
+        uint32_t t = 0xFFFFFFFFu;
+        if (mhz < below_mhz) t = __hip_atomic_fetch_add(queue, (uint32_t)PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *mailbox = t;
+    }
+    __syncthreads();
+    const uint32_t t = *mailbox;
+    __syncthreads(); // (the loop writes the mailbox again, two trips in)
+    return t;
+}
+
+// Leaving: this workgroup's ticket atomics have all returned; the last workgroup out resets the pair and then tells the
+// host (a word in host-coherent memory) that the pair may be handed to another launch.
+__device__ __forceinline__ void queue_sign_off(uint32_t *queue, uint32_t *queue_done, uint32_t queue_seq)
+{
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(queue + 1, 1u) == gridDim.x - 1) {
+            __hip_atomic_store(queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (queue_done) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // both zeroes have been performed device-wide
+                __hip_atomic_store(queue_done, queue_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+} // namespace
+
 // ---- the streaming kernel with a work queue ---------------------------------------------------------
 // Same lane layout, bursts, cache policies and arithmetic as modgpu_cycle_kernel<U, BLOCK, ALG, 2, MODE_FULL,
 // SAUX, 3> above; what differs is WHICH chunk a workgroup takes next.  With the static map (b, b+G, b+2G ...)
@@ -563,21 +607,7 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
         // ones from the ticket counter, or leaves at once.  (Helpers that stay and keep watching the clock were tried:
         // correct, but with 56 workgroups standing by the main ones ran 15 % slower at full clock --
         // profiles/r03_tune_dvfs.txt keeps that row.)
-        if (tid == 0) {
-            const uint64_t t0 = wall_clock64(), c0 = clock64();
-            uint64_t t1;
-            do {
-                __builtin_amdgcn_s_sleep(4);
-                t1 = wall_clock64();
-            } while (t1 - t0 < 200);
-            const uint64_t mhz = ((clock64() - c0) * 100) / (t1 - t0);
-            uint32_t t = 0xFFFFFFFFu;
-            if (mhz < a.helper_below_mhz) t = __hip_atomic_fetch_add(a.queue, (uint32_t)PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            q_next[0] = t;
-        }
-        __syncthreads();
-        const uint32_t t = q_next[0];
-        __syncthreads(); // (the loop below writes q_next[0] again, two trips in)
+        const uint32_t t = helper_first_ticket<PREFIX>(a.queue, a.helper_below_mhz, &q_next[0]);
         active = t != 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < NB; ++i) cq[i] = first + (uint32_t)PREFIX * Gm + t + (uint32_t)i;
@@ -607,19 +637,7 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
             }
         }
     }
-    // leave: this workgroup's ticket atomics have all returned; the last workgroup out resets the pair and then
-    // tells the host (a word in host-coherent memory) that the pair may be handed to another launch
-    if (tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (atomicAdd(a.queue + 1, 1u) == G - 1) {
-            __hip_atomic_store(a.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.queue_done) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // both zeroes have been performed device-wide
-                __hip_atomic_store(a.queue_done, a.queue_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
+    queue_sign_off(a.queue, a.queue_done, a.queue_seq);
 }
 
 // ---- the work-queue kernel over several parts in one launch (CycleBatchArgs, cycle_kernel.h) ------------------------
@@ -744,21 +762,7 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
         for (int i = 0; i < NB; ++i) cq[i] = blk + (uint32_t)i * Gm;
         last_static = blk + (uint32_t)NB * Gm;
     } else { // a helper workgroup: looks at the shader clock once, joins (tickets only) while it is low
-        if (tid == 0) {
-            const uint64_t t0 = wall_clock64(), c0 = clock64();
-            uint64_t t1;
-            do {
-                __builtin_amdgcn_s_sleep(4);
-                t1 = wall_clock64();
-            } while (t1 - t0 < 200);
-            const uint64_t mhz = ((clock64() - c0) * 100) / (t1 - t0);
-            uint32_t t = 0xFFFFFFFFu;
-            if (mhz < a.helper_below_mhz) t = __hip_atomic_fetch_add(a.queue, (uint32_t)PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            q_next[0] = t;
-        }
-        __syncthreads();
-        const uint32_t t = q_next[0];
-        __syncthreads();
+        const uint32_t t = helper_first_ticket<PREFIX>(a.queue, a.helper_below_mhz, &q_next[0]);
         active = t != 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < NB; ++i) cq[i] = (uint32_t)PREFIX * Gm + t + (uint32_t)i;
@@ -788,15 +792,5 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
             }
         }
     }
-    if (tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (atomicAdd(a.queue + 1, 1u) == G - 1) {
-            __hip_atomic_store(a.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.queue_done) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(a.queue_done, a.queue_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
+    queue_sign_off(a.queue, a.queue_done, a.queue_seq);
 }

@@ -23,7 +23,9 @@ host)         # profiles/r03_small_call_crossover.txt, r03_file_routes.txt, r03_
     MODGPU_DEVICE_ALIAS=8 modulate_amd/bin/modbench --parts 8 --steps 5 > gpurun_out/r03_parts.txt
     modulate_amd/bin/modbench --parts 1 --steps 20 >> gpurun_out/r03_parts.txt
     modulate_amd/bin/modbench 4294967296 20 3 >> gpurun_out/r03_parts.txt
-    python3 tools/bench_configs.py --out gpurun_out/r03_configs.json ;;
+    python3 tools/bench_configs.py --out gpurun_out/r03_configs.json
+    python3 tools/bench_batch.py > gpurun_out/r03_bench_batch.txt        # profiles/r03_parts_batched.txt
+    modulate_amd/bin/modbench --parts 8 --devices 0 --part-bytes 411000000 --steps 40 --warmup 5 >> gpurun_out/r03_bench_batch.txt ;;
 parity)       # profiles/r03_every_state.txt, r03_soak.txt, r03_numa.txt
     timeout -k 10 300 python3 tests/_every_state_child.py > gpurun_out/r03_every_state.txt
     timeout -k 10 600 python3 tools/soak.py 240 7 > gpurun_out/r03_soak.txt
