@@ -103,9 +103,14 @@ int Parts( int nParts, std::vector< int > devices, uint64_t n, int steps, int wa
         }
     TRY( pass() );
     for( int w = 1; w < warmup; ++w ) { TRY( pass() ); TRY( pass() ); }
+    modgpu_path_stats_t st0{}, st1{};
+    modgpu_path_stats( &st0, 0 );
     const double t0 = Now();
     for( int s = 0; s < steps; ++s ) { TRY( pass() ); TRY( pass() ); }
     const double dt = Now() - t0;
+    modgpu_path_stats( &st1, 0 );
+    modgpu_launch_info_t last{};
+    modgpu_last_launch( &last );
     for( int i = 0; i < nParts && ok; ++i )
     {
         TRY( modgpu_d2h( win.data(), (char*)parts[ i ] + ( n > win.size() ? n - win.size() : 0 ), std::min< uint64_t >( win.size(), n ), where[ i ] ) );
@@ -115,9 +120,11 @@ int Parts( int nParts, std::vector< int > devices, uint64_t n, int steps, int wa
     std::string devs;
     for( size_t i = 0; i < devices.size(); ++i ) devs += ( i ? "," : "" ) + std::to_string( devices[ i ] );
     std::printf( "{\"mode\": \"parts\", \"parts\": %d, \"devices\": [%s], \"logical_devices_visible\": %d, \"part_bytes\": %llu, \"steps\": %d, "
-                 "\"aggregate_payload_GBps\": %.1f, \"aggregate_hbm_read_write_GBps\": %.1f, \"ms_per_pass_over_all_parts\": %.4f, \"bit_exact_windows\": %s}\n",
+                 "\"aggregate_payload_GBps\": %.1f, \"aggregate_hbm_read_write_GBps\": %.1f, \"ms_per_pass_over_all_parts\": %.4f, "
+                 "\"kernel_launches_per_pass\": %.2f, \"last_kernel\": \"%s\", \"bit_exact_windows\": %s}\n",
                  nParts, devs.c_str(), avail, (unsigned long long)n, steps, 2.0 * steps * nParts * (double)n / dt / 1e9,
-                 4.0 * steps * nParts * (double)n / dt / 1e9, dt / ( 2.0 * steps ) * 1e3, ok ? "true" : "false" );
+                 4.0 * steps * nParts * (double)n / dt / 1e9, dt / ( 2.0 * steps ) * 1e3,
+                 (double)( st1.gpu_launches - st0.gpu_launches ) / ( 2.0 * steps ), last.kernel ? last.kernel : "?", ok ? "true" : "false" );
     for( int i = 0; i < nParts; ++i ) TRY( modgpu_free( parts[ i ], where[ i ] ) );
     return ok ? 0 : 2;
 }
