@@ -82,4 +82,34 @@ for k in range(1, 4):  # ta holds the keystream: replay 1 -> zeros, 2 -> keystre
     if k % 2:
         assert int(ta.sum(dtype=torch.int64).item()) == 0, "every byte back to zero"
 assert int(ta.sum(dtype=torch.int64).item()) == 0, "after an even number of passes in total the buffer is zero again"
+
+# (5) several parts in one launch (modgpu_cycle_batch_device) on torch memory: eager on a side stream, then captured -- the
+# part table travels in the kernel arguments, so the captured launch needs no allocation and replays with its own ticket pair
+sizes5 = [(120 << 20) + 7, 5, (90 << 20) + 1, 0, (70 << 20) + 16]
+ts = [torch.zeros(max(n, 1) + 8, dtype=torch.uint8, device="cuda") for n in sizes5]
+ptrs5 = [t.data_ptr() + 4 for t in ts]
+torch.cuda.synchronize()
+stats0 = M.queue_stats()
+with torch.cuda.stream(s1):
+    M.cycle_batch_device(ptrs5, sizes5, M.KEY_PS3, device=0, stream=s1.cuda_stream)
+assert M.last_launch()["variant"] == 3 and M.last_launch()["bytes"] == sum(sizes5)
+s1.synchronize()
+g5 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g5):
+    M.cycle_batch_device(ptrs5, sizes5, M.KEY_PS3, device=0, stream=torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+stats1 = M.queue_stats()
+assert stats1["batch_launches"] - stats0["batch_launches"] == 2 and stats1["graph"] - stats0["graph"] == 1, (stats0, stats1)
+for k in range(1, 4):  # eager pass left the keystream: replay 1 -> zeros, 2 -> keystream, 3 -> zeros
+    g5.replay()
+    torch.cuda.synchronize()
+    for t, n in zip(ts, sizes5):
+        got = t.cpu().numpy()
+        assert not got[:4].any() and not got[4 + n:].any(), "bytes around a part untouched"
+        if k % 2:
+            assert not got.any(), f"batch graph replay {k}"
+        elif n:
+            w = min(n, 1 << 20)
+            assert np.array_equal(got[4 + n - w:4 + n], O.keystream(M.KEY_PS3, w, n - w)), f"batch graph replay {k}"
+            assert np.array_equal(got[4:4 + min(n, 4096)], O.keystream(M.KEY_PS3, min(n, 4096), 0))
 print("TORCH_INTEROP_OK")
