@@ -100,6 +100,9 @@ def test_gpu_entry_points_fail_loudly_without_gpu(modgpu):
     with pytest.raises(modgpu.ModGpuError):
         modgpu.cycle_parts_host([buf], modgpu.KEY_PS4)
     with pytest.raises(modgpu.ModGpuError) as e:
+        modgpu.cycle_batch_device([buf.ctypes.data], [buf.size], modgpu.KEY_PS4, device=0)
+    assert e.value.code == 2 and np.array_equal(buf, keep)
+    with pytest.raises(modgpu.ModGpuError) as e:
         modgpu.DeviceBuffer(64)
     assert e.value.code == 2
     st = modgpu.path_stats()
