@@ -27,6 +27,8 @@ sys.path.insert(0, ROOT)
 # Read once when libmodgpu.so is loaded: forbids the library's host loop, so that nothing this script
 # times or checks can have been computed anywhere but on the GPU (the run fails instead).
 os.environ["MODGPU_REQUIRE_GPU"] = "1"
+# multi-rank runs: the host driver of this pool supports dmabuf IPC only (RCCL's barrier shares device memory across ranks)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
