@@ -29,7 +29,11 @@ bufs = [M.DeviceBuffer(cap), M.DeviceBuffer(cap)]
 streams = [hip_rt.Stream(), hip_rt.Stream()]
 t_end = time.time() + seconds
 n_cases = n_bytes = n_parts = 0
+t_note = time.time() + 60
 while time.time() < t_end:
+    if time.time() > t_note:  # (a run that prints nothing for minutes looks hung to the box's watchdog)
+        print(f"... {n_cases} buffers, {n_bytes / 1e9:.1f} GB so far", flush=True)
+        t_note = time.time() + 60
     shape = ["queue", "queue", "large", None][int(rng.integers(0, 4))]
     grid = int(rng.choice([1, 2, 3, 5, 8, 13, 24, 64, 200, 256]))
     M.debug_set_launch(shape, grid if shape else 0)
