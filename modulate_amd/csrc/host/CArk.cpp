@@ -579,7 +579,23 @@ eError CArk::BuildArkFromMemory( const char* lpData, uint64_t luDataSize )
     eError leError = SplitIntoArks();
     ERROR_RETURN;
     if( !maArkData.Allocate( luDataSize, PartSizes(), miPartDevices ) ) return eError_NoData;
-    if( luDataSize ) std::memcpy( maArkData.data(), lpData, (size_t)luDataSize );
+    // one thread copies 3.3 GB (BASELINE config 4) at ~10 GB/s; slices on several threads go at memory speed
+    const uint64_t luSlice = 32ull << 20;
+    const unsigned luThreads = (unsigned)std::min< uint64_t >( std::max( 1u, std::min( 16u, std::thread::hardware_concurrency() ) ), ( luDataSize + luSlice - 1 ) / luSlice );
+    if( luThreads <= 1 )
+    {
+        if( luDataSize ) std::memcpy( maArkData.data(), lpData, (size_t)luDataSize );
+        return eError_NoError;
+    }
+    std::atomic< uint64_t > lNext{ 0 };
+    auto lCopy = [ & ]() {
+        for( uint64_t luOff = lNext.fetch_add( luSlice ); luOff < luDataSize; luOff = lNext.fetch_add( luSlice ) )
+            std::memcpy( maArkData.data() + luOff, lpData + luOff, (size_t)std::min< uint64_t >( luSlice, luDataSize - luOff ) );
+    };
+    std::vector< std::thread > lThreads;
+    try { for( unsigned ii = 1; ii < luThreads; ++ii ) lThreads.emplace_back( lCopy ); } catch( ... ) {}
+    lCopy();
+    for( std::thread& t : lThreads ) t.join();
     return eError_NoError;
 }
 
