@@ -18,23 +18,21 @@ struct CycleArgs {
                          // addresses, so the first one starts `lead` bytes before the body and is masked there
     uint32_t base_head;  // state of the buffer's first byte
     uint32_t base_tail;  // state of the first tail byte
-    uint32_t *queue;     // work-queue shape only: {ticket counter, workgroups done}, both 0 at launch and 0 again at exit
-    uint32_t *queue_done; // work-queue shape: host-visible word that receives queue_seq once the pair is clean again (the host
-    uint32_t queue_seq;   // hands a pair out again only after it has seen that); nullptr: nobody waits for this pair
-    uint32_t main_groups;      // work-queue shape: workgroups [0, main_groups) stream from the start; the rest are HELPERS, which
-    uint32_t helper_below_mhz; // measure the shader clock when they start and join (tickets only) while it is below this many MHz,
-                               // else leave at once.  0 main_groups = every workgroup is a main one.
-    uint64_t *trace;     // nullptr in the product.  tools/tune_cycle's TRACE instantiation writes per-workgroup
-                         // timestamps here (wall_clock64, 100 MHz): [blk*32+0] start, [+1+k] end of trip k, [+31] XCC id
+    // tools/ only (the product plans a work-queue launch as a CycleQueueArgs directly): one buffer described this way is
+    // turned into a table of one part by cycle_queue_args_of() below
+    uint32_t *queue, *queue_done;
+    uint32_t queue_seq, main_groups, helper_below_mhz;
+    uint64_t *trace;     // nullptr in the product (TRACE instantiations of tools/tune_cycle)
 };
 
-// ---- several buffers in ONE launch of the work-queue shape (modgpu_cycle_batch_device) ------------------------------
-// A launch costs ~7 us of pipeline fill, finishing spread and gap to the next one: 5 % of a 411 MB part (BASELINE
-// config 4's part size).  Here the parts' chunks form one index space -- part p owns [start[p], start[p+1]) -- that the
-// same ticket counter hands out, so the fixed cost is paid once per batch.  Every part is its own keystream (its own
-// base states), has its own alignment (lead) and its own ragged edges.
+// ---- the work-queue shape: ONE launch over one or several buffers ---------------------------------------------------
+// Chunks are handed out by a ticket counter, so the kernel does not care whose chunk it is: the parts' chunks form one
+// index space -- part p owns [start[p], start[p+1]) -- and every part is its own keystream (its own base states), has
+// its own alignment (lead) and its own ragged edges.  A single buffer is a table of one part.  Several parts in a launch
+// pay the launch's fixed cost (~7 us: pipeline fill, finishing spread, gap to the next launch) once: that cost is 5 % of
+// a 411 MB part (BASELINE config 4's part size).  The table travels in the kernel arguments.
 constexpr int kCycleBatchMax = 16;
-struct CycleBatchPart {
+struct CycleQueuePart {
     uint8_t *body;      // 16-byte aligned start of the part's body
     uint64_t end;       // lead + body bytes: one past the body's last byte, counted from the chunk origin (body - lead)
     uint32_t lead;      // body address modulo the chunk size (the cut first chunk, if any, is not in the index space:
@@ -43,25 +41,58 @@ struct CycleBatchPart {
     uint32_t base_head, base_tail;
     uint32_t head_n, tail_n;
 };
-struct CycleBatchArgs {
-    uint32_t *queue, *queue_done; // as in CycleArgs
-    uint32_t queue_seq, main_groups, helper_below_mhz;
+struct CycleQueueArgs {
+    uint32_t *queue;      // {ticket counter, workgroups done}, both 0 at launch and 0 again at exit
+    uint32_t *queue_done; // host-visible word that receives queue_seq once the pair is clean again (the host hands a pair
+    uint32_t queue_seq;   // out again only after it has seen that); nullptr: nobody waits for this pair
+    uint32_t main_groups;      // workgroups [0, main_groups) stream from the start; the rest are HELPERS, which measure the
+    uint32_t helper_below_mhz; // shader clock when they start and join (tickets only) while it is below this many MHz, else
+                               // leave at once.  0 main_groups = every workgroup is a main one.
     uint32_t n_parts;                   // 1 .. kCycleBatchMax
     uint32_t start[kCycleBatchMax + 1]; // first global chunk index of each part; start[n_parts] = total; unused entries = total
-    CycleBatchPart part[kCycleBatchMax];
+    uint64_t *trace;     // nullptr in the product.  tools/tune_cycle's TRACE instantiation writes per-workgroup
+                         // timestamps here (wall_clock64, 100 MHz): [blk*32+0] start, [+1+k] end of trip k, [+31] XCC id
+    CycleQueuePart part[kCycleBatchMax];
 };
-uint32_t modgpu_batch_chunk_bytes();
-uint32_t modgpu_batch_block();
-const char *modgpu_batch_kernel_name();
-hipError_t modgpu_launch_cycle_batch(const CycleBatchArgs &a, uint32_t grid, hipStream_t stream);
+uint32_t modgpu_queue_chunk_bytes();
+uint32_t modgpu_queue_block();
+const char *modgpu_queue_kernel_name();
+hipError_t modgpu_launch_cycle_queue(const CycleQueueArgs &a, uint32_t grid, hipStream_t stream);
+
+// One buffer planned as a CycleArgs (chunk-aligned lead already folded into base_body) as the work-queue kernel's table
+// of one part.  chunk = the instantiation's bytes per workgroup trip.
+inline CycleQueueArgs cycle_queue_args_of(const CycleArgs &a, uint32_t chunk)
+{
+    CycleQueueArgs q{};
+    q.queue = a.queue;
+    q.queue_done = a.queue_done;
+    q.queue_seq = a.queue_seq;
+    q.main_groups = a.main_groups;
+    q.helper_below_mhz = a.helper_below_mhz;
+    q.trace = a.trace;
+    q.n_parts = 1;
+    CycleQueuePart &P = q.part[0];
+    P.body = static_cast<uint8_t *>(a.body);
+    P.lead = a.lead;
+    P.end = (uint64_t)a.lead + a.body_words * 16;
+    P.base_body = a.base_body;
+    P.base_head = a.base_head;
+    P.base_tail = a.base_tail;
+    P.head_n = a.head_n;
+    P.tail_n = a.tail_n;
+    const uint64_t n_chunks = (P.end + chunk - 1) / chunk, first = a.lead != 0 ? 1 : 0;
+    const uint32_t total = (uint32_t)(n_chunks > first ? n_chunks - first : 0);
+    for (int k = 1; k <= kCycleBatchMax; ++k) q.start[k] = total;
+    return q;
+}
 
 // Launch shapes.  A workgroup trip covers `chunk_bytes` contiguous bytes; the grid strides over
 // chunks.  grid * chunk_bytes / 4096 must stay <= 65536 (two-level tile jump table).
 enum CycleVariant : int {
     CYCLE_SMALL = 0, // 256 threads x 1 word : 4 KiB chunks, headers and other small buffers
     CYCLE_LARGE = 1, // 1024 threads x 8 words, software-pipelined, workgroup-synchronous bursts: 128 KiB chunks
-    CYCLE_QUEUE = 2, // the same shape, chunks handed out by a ticket counter (needs CycleArgs::queue; < 2^24 chunks)
-    CYCLE_BATCH = 3, // reporting only (modgpu_last_launch): the work-queue shape over several parts, CycleBatchArgs
+    CYCLE_QUEUE = 2, // persistent workgroups, 64 KiB chunks handed out by a ticket counter (CycleQueueArgs; < 2^24 chunks per part)
+    CYCLE_BATCH = 3, // reporting only (modgpu_last_launch): a work-queue launch that carried several parts
 };
 constexpr int kCycleVariants = 3;
 uint32_t modgpu_variant_chunk_bytes(int variant);

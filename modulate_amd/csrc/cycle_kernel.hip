@@ -26,8 +26,8 @@
 //   large   the same bursts with the static chunk map (b, b+G, ...), 128 KiB chunks, one workgroup per CU: what a
 //           launch takes when no ticket pair is free, or beyond 2^24 chunks.
 //   small   256 threads x one word, no pipeline: headers ... 256 MiB, and page-locked host memory across PCIe.
-// and the queue shape once more over SEVERAL buffers in one launch (modgpu_cycle_batch_kernel, CycleBatchArgs): an
-// archive's parts resident on one GPU share the launch's fixed cost; the part table travels in the kernel arguments.
+// The queue shape takes a TABLE of buffers (CycleQueueArgs; one buffer = a table of one): an archive's parts resident on one
+// GPU share one launch and pay its fixed cost once; the table travels in the kernel arguments.
 // DESIGN.md 3-4 has the measurements behind each of these choices.
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -59,7 +59,7 @@ template <int U, int BLOCK, int ALG, int SAUX> struct QueueShape {
     static constexpr uint32_t block = BLOCK;
     // product settings of the tuning-only template arguments: TRACE 0, DEPTH 1, MODE_FULL, nt loads, both
     // workgroup barriers (B1 in front of the load burst, B2 in front of the store burst)
-    static void launch(const CycleArgs &a, uint32_t grid, hipStream_t stream)
+    static void launch(const CycleQueueArgs &a, uint32_t grid, hipStream_t stream)
     {
         hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, ALG, SAUX, 0, 1, MODE_FULL, AUX_NT, 1, 1>), dim3(grid), dim3(BLOCK), 0, stream, a);
     }
@@ -81,31 +81,14 @@ using Large = Shape<8, 1024, 2, 2, AUX_SC1, 3>;
 // chip-wide), 512-thread workgroups and a second chunk of loads in flight lose 1 %; stores sc1+nt gain 0.5-1.8 %
 // over sc1 alone at every size
 using Queue = QueueShape<4, 1024, 2, AUX_SC1 | AUX_NT>;
-// several parts in one launch: the Queue shape over a global chunk index space (CycleBatchArgs)
-struct Batch {
-    static constexpr int U = 4, BLOCK = 1024, ALG = 2, SAUX = AUX_SC1 | AUX_NT;
-    static constexpr uint32_t chunk = (uint32_t)U * BLOCK * lcg::WORD;
-    static_assert(chunk == Queue::chunk, "the host plans a batch with the queue shape's chunk");
-    static void launch(const CycleBatchArgs &a, uint32_t grid, hipStream_t stream)
-    {
-        hipLaunchKernelGGL((modgpu_cycle_batch_kernel<U, BLOCK, ALG, SAUX, 1, AUX_NT>), dim3(grid), dim3(BLOCK), 0, stream, a);
-    }
-    static const char *name()
-    {
-        static char buf[96];
-        static const int n = std::snprintf(buf, sizeof buf, "modgpu_cycle_batch_kernel<%d, %d, %d, %d, 1, %d>", U, BLOCK, ALG, SAUX, (int)AUX_NT);
-        (void)n;
-        return buf;
-    }
-};
 } // namespace
 
-uint32_t modgpu_batch_chunk_bytes() { return Batch::chunk; }
-uint32_t modgpu_batch_block() { return Batch::BLOCK; }
-const char *modgpu_batch_kernel_name() { return Batch::name(); }
-hipError_t modgpu_launch_cycle_batch(const CycleBatchArgs &a, uint32_t grid, hipStream_t stream)
+uint32_t modgpu_queue_chunk_bytes() { return Queue::chunk; }
+uint32_t modgpu_queue_block() { return Queue::block; }
+const char *modgpu_queue_kernel_name() { return Queue::name(); }
+hipError_t modgpu_launch_cycle_queue(const CycleQueueArgs &a, uint32_t grid, hipStream_t stream)
 {
-    Batch::launch(a, grid, stream);
+    Queue::launch(a, grid, stream);
     return hipGetLastError();
 }
 
@@ -124,7 +107,7 @@ const char *modgpu_variant_kernel_name(int variant)
 
 hipError_t modgpu_launch_cycle(const CycleArgs &a, int variant, uint32_t grid, hipStream_t stream)
 {
-    if (variant == CYCLE_QUEUE) Queue::launch(a, grid, stream);
+    if (variant == CYCLE_QUEUE) Queue::launch(cycle_queue_args_of(a, Queue::chunk), grid, stream); // (tools; the product plans a table itself)
     else if (variant == CYCLE_LARGE) Large::launch(a, grid, stream);
     else Small::launch(a, grid, stream);
     return hipGetLastError();

@@ -402,50 +402,6 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
     }
 }
 
-// ---- pieces shared by the two work-queue kernels (one buffer / several parts) ------------------------
-namespace {
-// A HELPER workgroup's decision, made once when it starts (see modgpu_cycle_queue_kernel): lane 0 measures the shader
-// clock -- s_memtime ticks per 2 us of the constant 100 MHz counter -- and, while it is below `below_mhz`, draws the
-// workgroup's first PREFIX chunks from the ticket counter.  Returns the first ticket to every lane, 0xFFFFFFFF = leave.
-// `mailbox` is the workgroup's LDS ticket word 0, free again when this returns.
-template <int PREFIX> __device__ __forceinline__ uint32_t helper_first_ticket(uint32_t *queue, uint32_t below_mhz, uint32_t *mailbox)
-{
-    if (threadIdx.x == 0) {
-        const uint64_t t0 = wall_clock64(), c0 = clock64();
-        uint64_t t1;
-        do {
-            __builtin_amdgcn_s_sleep(4);
-            t1 = wall_clock64();
-        } while (t1 - t0 < 200);
-        const uint64_t mhz = ((clock64() - c0) * 100) / (t1 - t0);
-        uint32_t t = 0xFFFFFFFFu;
-        if (mhz < below_mhz) t = __hip_atomic_fetch_add(queue, (uint32_t)PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *mailbox = t;
-    }
-    __syncthreads();
-    const uint32_t t = *mailbox;
-    __syncthreads(); // (the loop writes the mailbox again, two trips in)
-    return t;
-}
-
-// Leaving: this workgroup's ticket atomics have all returned; the last workgroup out resets the pair and then tells the
-// host (a word in host-coherent memory) that the pair may be handed to another launch.
-__device__ __forceinline__ void queue_sign_off(uint32_t *queue, uint32_t *queue_done, uint32_t queue_seq)
-{
-    if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (atomicAdd(queue + 1, 1u) == gridDim.x - 1) {
-            __hip_atomic_store(queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (queue_done) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // both zeroes have been performed device-wide
-                __hip_atomic_store(queue_done, queue_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
-}
-} // namespace
-
 // ---- the streaming kernel with a work queue ---------------------------------------------------------
 // Same lane layout, bursts, cache policies and arithmetic as modgpu_cycle_kernel<U, BLOCK, ALG, 2, MODE_FULL,
 // SAUX, 3> above; what differs is WHICH chunk a workgroup takes next.  With the static map (b, b+G, b+2G ...)
@@ -455,6 +411,14 @@ __device__ __forceinline__ void queue_sign_off(uint32_t *queue, uint32_t *queue_
 // chunks are static (b, b+Gm, b+2Gm among the Gm main workgroups: no start-up latency) and every later one is a ticket from a global
 // counter, fetched a full trip before it is needed, so fast CUs simply take more chunks and all of them
 // finish within one trip of each other.
+//
+// The chunks on offer are those of a TABLE of parts (CycleQueueArgs, cycle_kernel.h): a global chunk index g belongs to the
+// part p with start[p] <= g < start[p+1], whose origin, end and base state come from the table in the kernel arguments (read
+// where it lies with scalar loads).  One buffer is a table of one part; an archive's parts resident on one GPU share a launch
+// and pay its fixed cost once.  A workgroup's consecutive chunks almost always lie in one part, so it keeps two cached views --
+// the chunk it is loading, the chunk it is finishing -- and walks the table only when a chunk falls outside its view (scalar
+// code, a handful of times per launch).  A view holds the part's base state already multiplied by this lane's share of the
+// jump (tile and lane powers), so a trip's first state is one multiply by the chunk's power, whatever the part.
 //
 // Ticket hand-off inside a workgroup: lane 0 issues the returning atomic right after a trip's second barrier
 // (in front of that trip's store burst, so waiting for it later never waits for those stores), publishes the
@@ -471,7 +435,7 @@ __device__ __forceinline__ void queue_sign_off(uint32_t *queue, uint32_t *queue_
 //         hand-off races; answers what a barrier-free workgroup would gain.  B2 = 2 (tools/tune_cycle): the
 //         barrier sits behind the store burst instead of in front of it (waves store as they finish)
 template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int LAUX = AUX_NT, int B1 = 1, int B2 = 1>
-__global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void modgpu_cycle_queue_kernel(CycleArgs a)
+__global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void modgpu_cycle_queue_kernel(CycleQueueArgs a)
 {
     static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
     static_assert(DEPTH >= 1 && DEPTH <= 3, "1..3 chunks of loads in flight");
@@ -483,6 +447,8 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
     const uint32_t blk = blockIdx.x;
     const uint32_t G = gridDim.x;
     const uint32_t Gm = a.main_groups != 0 && a.main_groups < G ? a.main_groups : G; // main workgroups; [Gm, G) are helpers (below)
+    const uint32_t n_parts = a.n_parts;
+    const uint32_t total = a.start[kCycleBatchMax]; // (unused entries of start[] hold the total as well)
     // Two LDS words, used alternately: a trip's ticket is written before that trip's barrier and read after it, and
     // the same word is written again two trips later -- i.e. behind the NEXT trip's barrier, which no wave can reach
     // before it has done this trip's read.  (With a single word, correctness would lean on the other barrier, the
@@ -499,48 +465,73 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
         if (tid == 0) a.trace[blk * 32 + 31] = __builtin_amdgcn_s_getreg((20 | (0 << 6) | (3 << 11)));
         stamp(0);
     }
-    if (blk == 0 && tid < 32) cycle_edges(a, tid);
-
-    const uint64_t lead = a.lead;
-    const uint64_t end = lead + a.body_words * lcg::WORD;
-    const uint32_t n_chunks = (uint32_t)((end + CHUNK - 1) / CHUNK); // host: < 2^24
-    uint8_t *const origin = static_cast<uint8_t *>(a.body) - lead;
     const uint32_t voff = tid * lcg::WORD;
+    // a^(4096*(tid/256)) * a^(16*(tid%256)): this lane's word 0 relative to the start of any chunk
+    const uint32_t lane_mul = mulmod_canon(c_tile_lo.v[tid >> 8], c_lane_pow.v[tid & 255]);
 
-    // state of this lane's word 0 in chunk 0; chunk c multiplies it by a^(CHUNK*c)
-    const uint32_t lane0 = mulmod_canon(mulmod_canon(a.base_body, c_tile_lo.v[tid >> 8]), c_lane_pow.v[tid & 255]);
-    auto states = [&](uint32_t c, uint32_t(&s)[U]) {
-        uint32_t p = mulmod_canon(c_chunk_pow0<CHUNK>.v[c & 255], c_chunk_pow1<CHUNK>.v[(c >> 8) & 255]);
-        p = mulmod_canon(p, c_chunk_pow2<CHUNK>.v[(c >> 16) & 255]);
-        s[0] = mulmod_canon(lane0, p);
-#pragma unroll
-        for (int u = 1; u < U; ++u) s[u] = mulmod_canon(s[u - 1], lcg::kTileLo.v[BLOCK / 256]);
-    };
-
-    // chunk 0 is cut at the front when the body is not chunk-aligned: workgroup 0 peels it off (see
-    // modgpu_cycle_kernel), and chunk numbering for everybody starts at 1
-    const uint32_t first = lead != 0 ? 1u : 0u;
-    if (blk == 0 && lead != 0) {
-        const uint64_t inside = end < CHUNK ? end - lead : CHUNK - lead;
-        auto r = __builtin_amdgcn_make_buffer_rsrc(static_cast<uint8_t *>(a.body), 0, (int)inside, 0x00020000);
-        uint32_t su = lane0;
+    // Ragged edges (< 16 bytes before / after a part's aligned body) and the part's first chunk when the body is not
+    // chunk-aligned: workgroup p does them for part p, before the stream starts (cold code).  Chunks sit on ABSOLUTE
+    // chunk-aligned addresses, so that first chunk is cut at the front: descriptor based at the body, per-lane offset minus
+    // `lead`; lanes in front of the body get a negative offset, which wraps far past num_records, so the hardware range check
+    // drops their loads and stores.  It is not part of the chunk index space.
+    for (uint32_t p = blk; p < n_parts; p += G) {
+        const CycleQueuePart &P = a.part[p];
+        const uint64_t body_bytes = P.end - P.lead;
+        if (tid < 32) cycle_edges(P.body - P.head_n, P.head_n, P.base_head, P.body + body_bytes, P.tail_n, P.base_tail, tid);
+        if (P.lead != 0 && body_bytes != 0) {
+            const uint64_t inside = P.end < CHUNK ? body_bytes : CHUNK - P.lead;
+            auto r = __builtin_amdgcn_make_buffer_rsrc(P.body, 0, (int)inside, 0x00020000);
+            uint32_t su = mulmod_canon(P.base_body, lane_mul);
 #pragma unroll 1
-        for (uint32_t u = 0; u < (uint32_t)U; ++u) {
-            const uint32_t o = voff + u * SUB - (uint32_t)lead;
-            u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, AUX_NT);
-            d = cycle_word<ALG>(d, su);
-            __builtin_amdgcn_raw_buffer_store_b128(d, r, o, 0, SAUX);
-            su = mulmod_canon(su, lcg::kTileLo.v[BLOCK / 256]);
+            for (uint32_t u = 0; u < (uint32_t)U; ++u) {
+                const uint32_t o = voff + u * SUB - P.lead;
+                u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, AUX_NT);
+                d = cycle_word<ALG>(d, su);
+                __builtin_amdgcn_raw_buffer_store_b128(d, r, o, 0, SAUX);
+                su = mulmod_canon(su, lcg::kTileLo.v[BLOCK / 256]);
+            }
         }
     }
 
-    auto rsrc_at = [&](uint32_t c) {
-        const uint64_t o = (uint64_t)c * CHUNK;
-        const uint64_t left = o < end ? end - o : 0; // a chunk past the end: zero-size descriptor, loads give 0, stores drop
-        return __builtin_amdgcn_make_buffer_rsrc(origin + o, 0, (int)(left < CHUNK ? left : CHUNK), 0x00020000);
+    // the part a global chunk index lies in, as far as the loop needs it
+    struct View {
+        uint8_t *origin;    // body - lead
+        uint64_t end;
+        uint32_t lo, hi;    // global indices [lo, hi) map to the part's chunks first + (g - lo)
+        uint32_t first;     // 1 if the part's chunk 0 is the cut one (done above)
+        uint32_t lane_base; // per lane: state of this lane's word 0 in the part's chunk 0
     };
-    auto load = [&](u32x4(&d)[U], uint32_t c) {
-        auto r = rsrc_at(c);
+    auto locate = [&](uint32_t g, View &v) {
+        if (g - v.lo < v.hi - v.lo) return; // lo <= g < hi
+        uint32_t p = 0;
+#pragma unroll 1
+        for (uint32_t i = 1; i < n_parts; ++i) p += g >= a.start[i] ? 1u : 0u; // (empty parts share their start with the next one: skipped)
+        const CycleQueuePart &P = a.part[p];
+        v.origin = P.body - P.lead;
+        v.end = P.end;
+        v.first = P.lead != 0 ? 1u : 0u;
+        v.lo = a.start[p];
+        v.hi = a.start[p + 1];
+        v.lane_base = mulmod_canon(P.base_body, lane_mul);
+    };
+    auto rsrc_at = [&](uint32_t g, const View &v) {
+        const uint64_t o = (uint64_t)(v.first + (g - v.lo)) * CHUNK;
+        const uint64_t left = g < v.hi && o < v.end ? v.end - o : 0; // past the last part: zero-size descriptor, loads give 0, stores drop
+        return __builtin_amdgcn_make_buffer_rsrc(v.origin + o, 0, (int)(left < CHUNK ? left : CHUNK), 0x00020000);
+    };
+    // states of this lane's U words in chunk g: the part's chunk c multiplies lane_base by a^(CHUNK*c), c < 2^24 (host)
+    auto states = [&](uint32_t g, const View &v, uint32_t(&s)[U]) {
+        const uint32_t c = v.first + (g - v.lo);
+        uint32_t p = mulmod_canon(c_chunk_pow0<CHUNK>.v[c & 255], c_chunk_pow1<CHUNK>.v[(c >> 8) & 255]);
+        p = mulmod_canon(p, c_chunk_pow2<CHUNK>.v[(c >> 16) & 255]);
+        s[0] = mulmod_canon(v.lane_base, p);
+#pragma unroll
+        for (int u = 1; u < U; ++u) s[u] = mulmod_canon(s[u - 1], lcg::kTileLo.v[BLOCK / 256]);
+    };
+    View vl{nullptr, 0, 0, 0, 0, 1}, vs{nullptr, 0, 0, 0, 0, 1}; // load side, store side
+    auto load = [&](u32x4(&d)[U], uint32_t g) {
+        locate(g, vl);
+        auto r = rsrc_at(g, vl);
 #pragma unroll
         for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, LAUX);
     };
@@ -554,15 +545,16 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
     uint32_t pending = 0; // lane 0: the ticket in flight
     const uint32_t q_next_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&q_next[0];
     const uint32_t one = 1u;
-    // one trip: chunk c's words are in d; compute, publish last trip's ticket, barrier, fetch a ticket, store burst
-    auto process_store = [&](u32x4(&d)[U], uint32_t c, bool publish) {
-        auto r = rsrc_at(c);
+    // one trip: chunk g's words are in d; compute, publish last trip's ticket, barrier, fetch a ticket, store burst
+    auto process_store = [&](u32x4(&d)[U], uint32_t g, bool publish) {
+        locate(g, vs);
+        auto r = rsrc_at(g, vs);
         if constexpr (MODE == MODE_COPY) {
 #pragma unroll
             for (int u = 0; u < U; ++u) d[u] = ~d[u];
         } else {
             uint32_t s[U];
-            states(c, s);
+            states(g, vs, s);
 #pragma unroll
             for (int u = 0; u < U; ++u) d[u] = cycle_word<ALG>(d[u], s[u]);
         }
@@ -583,10 +575,10 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
     auto take_published = [&]() { // every lane, after the trip's barrier (trip already counted: the word is (trip-1)&1)
         uint32_t t;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(q_next_lds + 4u * ((trip - 1u) & 1u)) : "memory");
-        return first + (uint32_t)PREFIX * Gm + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        return (uint32_t)PREFIX * Gm + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     };
 
-    // A workgroup's chunk sequence: positions 0 .. PREFIX-1 are static (b, b+G, ...), position j + PREFIX is the
+    // A workgroup's chunk sequence: positions 0 .. PREFIX-1 are static (b, b+Gm, ...), position j + PREFIX is the
     // ticket fetched in trip j.  cq[] holds positions k .. k+DEPTH at the start of trip k: cq[0] is computed,
     // cq[DEPTH] is loaded now, the ones between are already in flight.
     uint32_t cq[NB];
@@ -594,8 +586,8 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
     bool active = true;
     if (blk < Gm) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) cq[i] = first + blk + (uint32_t)i * Gm;
-        last_static = first + blk + (uint32_t)NB * Gm;
+        for (int i = 0; i < NB; ++i) cq[i] = blk + (uint32_t)i * Gm;
+        last_static = blk + (uint32_t)NB * Gm;
     } else {
         // A HELPER workgroup.  With the chip's clock where it normally is (2.1-2.2 GHz) the 25-per-32-CU main workgroups
         // saturate HBM and more streams only hurt (-1.8 % at one per CU).  For the first ~10 ms after load onset,
@@ -607,13 +599,27 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
         // ones from the ticket counter, or leaves at once.  (Helpers that stay and keep watching the clock were tried:
         // correct, but with 56 workgroups standing by the main ones ran 15 % slower at full clock --
         // profiles/r03_tune_dvfs.txt keeps that row.)
-        const uint32_t t = helper_first_ticket<PREFIX>(a.queue, a.helper_below_mhz, &q_next[0]);
+        uint32_t t = 0xFFFFFFFFu;
+        if (tid == 0) {
+            const uint64_t t0 = wall_clock64(), c0 = clock64();
+            uint64_t t1;
+            do {
+                __builtin_amdgcn_s_sleep(4);
+                t1 = wall_clock64();
+            } while (t1 - t0 < 200);
+            const uint64_t mhz = ((clock64() - c0) * 100) / (t1 - t0);
+            if (mhz < a.helper_below_mhz) t = __hip_atomic_fetch_add(a.queue, (uint32_t)PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q_next[0] = t;
+        }
+        __syncthreads();
+        t = q_next[0];
+        __syncthreads(); // (the loop below writes q_next[0] again, two trips in)
         active = t != 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) cq[i] = first + (uint32_t)PREFIX * Gm + t + (uint32_t)i;
-        last_static = first + (uint32_t)PREFIX * Gm + t + (uint32_t)NB;
+        for (int i = 0; i < NB; ++i) cq[i] = (uint32_t)PREFIX * Gm + t + (uint32_t)i;
+        last_static = (uint32_t)PREFIX * Gm + t + (uint32_t)NB;
     }
-    if (active && cq[0] < n_chunks) {
+    if (active && cq[0] < total) {
         u32x4 d[NB][U];
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) load(d[i], cq[i]);
@@ -630,161 +636,6 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
                 for (int i = 0; i < DEPTH; ++i) cq[i] = cq[i + 1];
                 cq[DEPTH] = publish ? take_published() : last_static;
                 publish = true;
-                if (cq[0] >= n_chunks) {
-                    finished = true;
-                    break;
-                }
-            }
-        }
-    }
-    queue_sign_off(a.queue, a.queue_done, a.queue_seq);
-}
-
-// ---- the work-queue kernel over several parts in one launch (CycleBatchArgs, cycle_kernel.h) ------------------------
-// The loop, the bursts, the ticket hand-off, the helper workgroups and the exit are modgpu_cycle_queue_kernel's (the
-// comments there apply); what differs is that a chunk index g is global: it belongs to the part p with
-// start[p] <= g < start[p+1], whose origin, end and base state come from the table in the kernel arguments.  A workgroup's
-// consecutive chunks almost always lie in the same part, so it keeps two cached views -- one for the chunk it is loading,
-// one for the chunk it is finishing -- and walks the table only when a chunk falls outside its view (scalar code, a
-// handful of times per launch).  The part-independent half of a lane's jump (tile and lane powers) is computed once.
-template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int DEPTH = 1, int LAUX = AUX_NT>
-__global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void modgpu_cycle_batch_kernel(CycleBatchArgs a)
-{
-    static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
-    static_assert(DEPTH >= 1 && DEPTH <= 3, "1..3 chunks of loads in flight");
-    constexpr uint32_t CHUNK = (uint32_t)U * BLOCK * lcg::WORD;
-    constexpr uint32_t SUB = BLOCK * lcg::WORD;
-    constexpr int NB = DEPTH + 1;
-    constexpr int PREFIX = DEPTH + 2;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t blk = blockIdx.x;
-    const uint32_t G = gridDim.x;
-    const uint32_t Gm = a.main_groups != 0 && a.main_groups < G ? a.main_groups : G;
-    const uint32_t n_parts = a.n_parts;
-    const uint32_t total = a.start[kCycleBatchMax]; // (unused entries of start[] hold the total as well)
-    __shared__ uint32_t q_next[2];
-    uint32_t trip = 0;
-    const uint32_t voff = tid * lcg::WORD;
-    // a^(4096*(tid/256)) * a^(16*(tid%256)): this lane's word 0 relative to the start of any chunk
-    const uint32_t lane_mul = mulmod_canon(c_tile_lo.v[tid >> 8], c_lane_pow.v[tid & 255]);
-
-    // ragged edges and the cut first chunk of part p: workgroup p (cold code, before the stream starts)
-    for (uint32_t p = blk; p < n_parts; p += G) {
-        const CycleBatchPart &P = a.part[p];
-        const uint64_t body_bytes = P.end - P.lead;
-        if (tid < 32) cycle_edges(P.body - P.head_n, P.head_n, P.base_head, P.body + body_bytes, P.tail_n, P.base_tail, tid);
-        if (P.lead != 0 && body_bytes != 0) {
-            const uint64_t inside = P.end < CHUNK ? body_bytes : CHUNK - P.lead;
-            auto r = __builtin_amdgcn_make_buffer_rsrc(P.body, 0, (int)inside, 0x00020000);
-            uint32_t su = mulmod_canon(P.base_body, lane_mul);
-#pragma unroll 1
-            for (uint32_t u = 0; u < (uint32_t)U; ++u) {
-                const uint32_t o = voff + u * SUB - P.lead; // lanes in front of the body wrap far past num_records: dropped
-                u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, AUX_NT);
-                d = cycle_word<ALG>(d, su);
-                __builtin_amdgcn_raw_buffer_store_b128(d, r, o, 0, SAUX);
-                su = mulmod_canon(su, lcg::kTileLo.v[BLOCK / 256]);
-            }
-        }
-    }
-
-    // the part a global chunk index lies in, as far as the loop needs it
-    struct View {
-        uint8_t *origin;  // body - lead
-        uint64_t end;
-        uint32_t base;    // state at the origin
-        uint32_t lo, hi;  // global indices [lo, hi) map to local chunks first + (g - lo)
-        uint32_t first;   // 1 if the part's chunk 0 is the cut one (done above)
-    };
-    auto locate = [&](uint32_t g, View &v) {
-        if (g - v.lo < v.hi - v.lo) return; // lo <= g < hi
-        uint32_t p = 0;
-#pragma unroll 1
-        for (uint32_t i = 1; i < n_parts; ++i) p += g >= a.start[i] ? 1u : 0u; // (empty parts share their start with the next one: skipped)
-        const CycleBatchPart &P = a.part[p];
-        v.origin = P.body - P.lead;
-        v.end = P.end;
-        v.base = P.base_body;
-        v.first = P.lead != 0 ? 1u : 0u;
-        v.lo = a.start[p];
-        v.hi = a.start[p + 1];
-    };
-    auto rsrc_at = [&](uint32_t g, const View &v) {
-        const uint64_t o = (uint64_t)(v.first + (g - v.lo)) * CHUNK;
-        const uint64_t left = g < v.hi && o < v.end ? v.end - o : 0; // past the part (only ever: past the last part): zero-size descriptor
-        return __builtin_amdgcn_make_buffer_rsrc(v.origin + o, 0, (int)(left < CHUNK ? left : CHUNK), 0x00020000);
-    };
-    auto states = [&](uint32_t g, const View &v, uint32_t(&s)[U]) {
-        const uint32_t c = v.first + (g - v.lo);
-        uint32_t p = mulmod_canon(c_chunk_pow0<CHUNK>.v[c & 255], c_chunk_pow1<CHUNK>.v[(c >> 8) & 255]);
-        p = mulmod_canon(p, c_chunk_pow2<CHUNK>.v[(c >> 16) & 255]);
-        s[0] = mulmod_canon(mulmod_canon(v.base, p), lane_mul);
-#pragma unroll
-        for (int u = 1; u < U; ++u) s[u] = mulmod_canon(s[u - 1], lcg::kTileLo.v[BLOCK / 256]);
-    };
-    View vl{nullptr, 0, 1, 0, 0, 0}, vs{nullptr, 0, 1, 0, 0, 0}; // load side, store side
-    auto load = [&](u32x4(&d)[U], uint32_t g) {
-        locate(g, vl);
-        auto r = rsrc_at(g, vl);
-#pragma unroll
-        for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, LAUX);
-    };
-    uint32_t pending = 0;
-    const uint32_t q_next_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&q_next[0];
-    const uint32_t one = 1u;
-    auto process_store = [&](u32x4(&d)[U], uint32_t g, bool publish) {
-        locate(g, vs);
-        auto r = rsrc_at(g, vs);
-        uint32_t s[U];
-        states(g, vs, s);
-#pragma unroll
-        for (int u = 0; u < U; ++u) d[u] = cycle_word<ALG>(d[u], s[u]);
-        if (publish && tid == 0)
-            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(q_next_lds + 4u * (trip & 1u)), "v"(pending) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        if (tid == 0) pending = __hip_atomic_fetch_add(a.queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
-        ++trip;
-    };
-    auto take_published = [&]() {
-        uint32_t t;
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(q_next_lds + 4u * ((trip - 1u) & 1u)) : "memory");
-        return (uint32_t)PREFIX * Gm + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-    };
-
-    uint32_t cq[NB];
-    uint32_t last_static;
-    bool active = true;
-    if (blk < Gm) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) cq[i] = blk + (uint32_t)i * Gm;
-        last_static = blk + (uint32_t)NB * Gm;
-    } else { // a helper workgroup: looks at the shader clock once, joins (tickets only) while it is low
-        const uint32_t t = helper_first_ticket<PREFIX>(a.queue, a.helper_below_mhz, &q_next[0]);
-        active = t != 0xFFFFFFFFu;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) cq[i] = (uint32_t)PREFIX * Gm + t + (uint32_t)i;
-        last_static = (uint32_t)PREFIX * Gm + t + (uint32_t)NB;
-    }
-    if (active && cq[0] < total) {
-        u32x4 d[NB][U];
-#pragma unroll
-        for (int i = 0; i < DEPTH; ++i) load(d[i], cq[i]);
-        bool publish = false;
-        bool finished = false;
-        while (!finished) {
-#pragma unroll
-            for (int p = 0; p < NB; ++p) {
-                __builtin_amdgcn_s_barrier();
-                load(d[(p + DEPTH) % NB], cq[DEPTH]);
-                __builtin_amdgcn_sched_barrier(0);
-                process_store(d[p], cq[0], publish);
-#pragma unroll
-                for (int i = 0; i < DEPTH; ++i) cq[i] = cq[i + 1];
-                cq[DEPTH] = publish ? take_published() : last_static;
-                publish = true;
                 if (cq[0] >= total) {
                     finished = true;
                     break;
@@ -792,5 +643,17 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
             }
         }
     }
-    queue_sign_off(a.queue, a.queue_done, a.queue_seq);
+    // leave: this workgroup's ticket atomics have all returned; the last workgroup out resets the pair and then
+    // tells the host (a word in host-coherent memory) that the pair may be handed to another launch
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(a.queue + 1, 1u) == G - 1) {
+            __hip_atomic_store(a.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.queue_done) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // both zeroes have been performed device-wide
+                __hip_atomic_store(a.queue_done, a.queue_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }

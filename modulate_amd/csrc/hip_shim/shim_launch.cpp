@@ -3,8 +3,6 @@
 // (CycleArgs: head / body / tail pointers, the three base states, `lead`), what the kernel would do to the same
 // bytes -- with the product's own Park-Miller arithmetic (lcg.h), byte by byte.  So the sanitizer runs check the
 // host's planning (splits, jump-ahead states, alignment lead) as well as its memory and thread discipline.
-// The work-queue shape's ticket pair is emulated: taken at the start of the launch, cleaned and signed off at its
-// end, and a launch that finds its pair taken counts a collision.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -31,20 +29,10 @@ void run(void *arg)
 {
     Launch *l = static_cast<Launch *>(arg);
     const CycleArgs &a = l->a;
-    const bool queue = l->variant == CYCLE_QUEUE && a.queue;
-    if (queue) {
-        uint32_t expect = 0;
-        if (!std::atomic_ref<uint32_t>(a.queue[0]).compare_exchange_strong(expect, 1u)) g_collisions.fetch_add(1); // another launch holds this pair
-        std::this_thread::sleep_for(std::chrono::microseconds(200)); // a launch lasts a while: overlaps become likely
-    }
     span(a.head_ptr, a.head_n, a.base_head);
     // base_body is the state `lead` bytes before the body
     span(static_cast<uint8_t *>(a.body), a.body_words * lcg::WORD, lcg::mulmod(a.base_body, lcg::powmod(lcg::A, a.lead)));
     span(a.tail_ptr, a.tail_n, a.base_tail);
-    if (queue) {
-        std::atomic_ref<uint32_t>(a.queue[0]).store(0u);
-        if (a.queue_done) std::atomic_ref<uint32_t>(*a.queue_done).store(a.queue_seq, std::memory_order_release);
-    }
     g_launches[l->variant].fetch_add(1);
     delete l;
 }
@@ -60,19 +48,20 @@ hipError_t modgpu_launch_cycle(const CycleArgs &a, int variant, uint32_t, hipStr
     return hipSuccess;
 }
 
-// several parts in one launch: the same, part by part, from the batch plan (start[] must tile the chunk index space)
+// the work-queue shape: the same, part by part, from the table (start[] must tile the chunk index space).  The ticket pair is
+// emulated: taken at the start of the launch, cleaned and signed off at its end; a launch that finds its pair taken counts a collision.
 namespace {
 std::atomic<unsigned long long> g_batch_launches{0}, g_batch_plan_errors{0};
 void run_batch(void *arg)
 {
-    CycleBatchArgs *b = static_cast<CycleBatchArgs *>(arg);
+    CycleQueueArgs *b = static_cast<CycleQueueArgs *>(arg);
     uint32_t expect = 0;
-    if (!std::atomic_ref<uint32_t>(b->queue[0]).compare_exchange_strong(expect, 1u)) g_collisions.fetch_add(1);
-    std::this_thread::sleep_for(std::chrono::microseconds(200));
-    const uint64_t chunk = modgpu_batch_chunk_bytes();
+    if (!std::atomic_ref<uint32_t>(b->queue[0]).compare_exchange_strong(expect, 1u)) g_collisions.fetch_add(1); // another launch holds this pair
+    std::this_thread::sleep_for(std::chrono::microseconds(200)); // a launch lasts a while: overlaps become likely
+    const uint64_t chunk = modgpu_queue_chunk_bytes();
     uint64_t total = 0;
     for (uint32_t p = 0; p < b->n_parts; ++p) {
-        const CycleBatchPart &P = b->part[p];
+        const CycleQueuePart &P = b->part[p];
         const uint64_t body_bytes = P.end - P.lead, n_chunks = (P.end + chunk - 1) / chunk, first = P.lead != 0 ? 1 : 0;
         if (b->start[p] != total || (reinterpret_cast<uintptr_t>(P.body) & (chunk - 1)) != P.lead) g_batch_plan_errors.fetch_add(1);
         total += n_chunks > first ? n_chunks - first : 0;
@@ -84,16 +73,17 @@ void run_batch(void *arg)
         if (b->start[p] != total) g_batch_plan_errors.fetch_add(1);
     std::atomic_ref<uint32_t>(b->queue[0]).store(0u);
     if (b->queue_done) std::atomic_ref<uint32_t>(*b->queue_done).store(b->queue_seq, std::memory_order_release);
-    g_batch_launches.fetch_add(1);
+    if (b->n_parts > 1) g_batch_launches.fetch_add(1);
+    g_launches[CYCLE_QUEUE].fetch_add(1);
     delete b;
 }
 } // namespace
-uint32_t modgpu_batch_chunk_bytes() { return 65536u; }
-uint32_t modgpu_batch_block() { return 1024u; }
-const char *modgpu_batch_kernel_name() { return "shim batch"; }
-hipError_t modgpu_launch_cycle_batch(const CycleBatchArgs &a, uint32_t, hipStream_t stream)
+uint32_t modgpu_queue_chunk_bytes() { return 65536u; }
+uint32_t modgpu_queue_block() { return 1024u; }
+const char *modgpu_queue_kernel_name() { return "shim queue"; }
+hipError_t modgpu_launch_cycle_queue(const CycleQueueArgs &a, uint32_t, hipStream_t stream)
 {
-    shim::enqueue(stream, run_batch, new CycleBatchArgs(a));
+    shim::enqueue(stream, run_batch, new CycleQueueArgs(a));
     return hipSuccess;
 }
 extern "C" unsigned long long modgpu_shim_batch_launches(void) { return g_batch_launches.load(); }

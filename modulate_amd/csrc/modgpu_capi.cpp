@@ -186,8 +186,6 @@ struct Plan {
     CycleArgs args;
     int variant;
     uint32_t grid;
-    int queue_line = -1; // ring line held by this launch (given back if the launch fails), with its device
-    int queue_dev = -1;
 };
 
 // the calling thread's last launch (modgpu_last_launch: reporting only)
@@ -405,7 +403,18 @@ void queue_grid(uint64_t chunks, uint64_t cus, uint64_t *main_cap, uint64_t *hel
     *main_cap = cap;
 }
 
-Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off, bool over_pcie, hipStream_t stream)
+// The launch shape a single buffer takes by its size (or the one the testing flavour forces).
+int choose_variant(const void *dev_buf, uint64_t n, bool over_pcie)
+{
+    const int forced = forced_variant();
+    if (forced >= 0 && forced < kCycleVariants) return forced;
+    const uint64_t head = std::min<uint64_t>(n, (16 - (reinterpret_cast<uintptr_t>(dev_buf) & 15)) & 15);
+    const uint64_t body_bytes = (n - head) / 16 * 16;
+    return body_bytes >= kLargeMin && !over_pcie ? CYCLE_QUEUE : CYCLE_SMALL;
+}
+
+// The small shape or the streaming shape with the static chunk map (the work-queue shape is planned by launch_queue).
+Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off, bool over_pcie, int variant)
 {
     Plan p{};
     uintptr_t addr = reinterpret_cast<uintptr_t>(dev_buf);
@@ -427,103 +436,50 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
     a.base_tail = lcg::state_residue(key_res, o + head + (words * 16) % lcg::PERIOD);
 
     uint64_t body_bytes = words * 16;
-    p.variant = body_bytes >= kLargeMin && !over_pcie ? CYCLE_QUEUE : CYCLE_SMALL;
-    const int forced = forced_variant();
-    if (forced >= 0 && forced < kCycleVariants) p.variant = forced;
-    uint64_t chunk = modgpu_variant_chunk_bytes(p.variant);
-    if (p.variant == CYCLE_QUEUE) { // needs a clean ticket pair of its own and chunk indices that fit its 3-byte jump tables
-        QueuePair q;
-        if ((body_bytes + chunk) / chunk + 4ull * 2048 < (1ull << 24)) q = queue_pair(stream);
-        a.queue = q.pair;
-        a.queue_done = q.done;
-        a.queue_seq = q.seq;
-        p.queue_line = q.line;
-        p.queue_dev = q.dev;
-        if (!a.queue) {
-            p.variant = CYCLE_LARGE;
-            chunk = modgpu_variant_chunk_bytes(p.variant);
-        }
-    }
+    p.variant = variant == CYCLE_SMALL ? CYCLE_SMALL : CYCLE_LARGE;
+    const uint64_t chunk = modgpu_variant_chunk_bytes(p.variant);
     // chunks sit on absolute chunk-aligned addresses: the first starts `lead` bytes before the body,
     // and the kernel counts positions from there, so its base state is stepped back by a^(-lead)
     a.lead = (uint32_t)(reinterpret_cast<uintptr_t>(a.body) & (chunk - 1));
     a.base_body = lcg::mulmod(a.base_body, lcg::powmod(lcg::A, lcg::PERIOD - a.lead % lcg::PERIOD));
     uint64_t chunks = (a.lead + body_bytes + chunk - 1) / chunk;
     uint64_t cap = p.variant == CYCLE_SMALL ? kSmallGridMax : large_grid();
-    // With chunks handed out by tickets any grid finishes the job, and the memory system does best with fewer
-    // streams than CUs: 25 workgroups per 32 CUs (200 on MI355X) -- measured plateau 184..208, +1.6 % at 4 GiB and
-    // +2.4 % at 402 MiB over one per CU; 160 and below fall off (profiles/r02_tune_cycle_queue_grid.txt).
-    // ... at the clock the chip normally runs at.  While power management holds the shader clock low (the first ~10 ms after
-    // load onset) the kernel is bound by its arithmetic instead, and the CUs left idle are worth more than the tidy memory
-    // pattern: they get a HELPER workgroup each, which measures the clock when it starts and joins the ticket queue only
-    // while it is below MODGPU_HELPER_BELOW_MHZ (default 1850; cycle_kernel_impl.h; profiles/r03_first_pass.txt, r03_tune_dvfs.txt).
-    uint64_t helpers = 0;
     const uint32_t grid_cap = forced_grid_cap();
-    if (p.variant == CYCLE_QUEUE) {
-        queue_grid(chunks, cap, &cap, &helpers);
-    } else if (grid_cap >= 1 && grid_cap < cap) {
-        cap = grid_cap;
-    }
+    if (grid_cap >= 1 && grid_cap < cap) cap = grid_cap;
     if (over_pcie) cap = std::min<uint64_t>(cap, kPcieGridMax);
-    const uint64_t main_groups = std::max<uint64_t>(1, std::min<uint64_t>(chunks, cap));
-    p.grid = (uint32_t)(main_groups + helpers);
-    a.main_groups = (uint32_t)main_groups;
-    a.helper_below_mhz = helper_mode() == 1 ? 0xFFFFFFFFu : helper_below_mhz();
+    p.grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(chunks, cap));
     // one grid trip advances every lane-word by grid chunks
     a.stride_mul2 = 2u * lcg::powmod(lcg::A, ((uint64_t)p.grid * chunk) % lcg::PERIOD);
     return p;
 }
 
-} // namespace
-
-int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off, hipStream_t stream, bool over_pcie)
+// One launch of the work-queue shape over parts[0..n) -- 1..kCycleBatchMax non-empty buffers of the current device, each its
+// own keystream.  Returns MODGPU_OK, an error, or 1: not possible right now (no ticket pair free -- every ring line busy, or a
+// capture with the graph pool used up -- or a part beyond the kernel's three-byte chunk jump tables): the caller takes a shape
+// that needs no pair.
+int launch_queue(void *const *bufs, const uint64_t *sizes, const uint64_t *offs, int n, uint32_t key_res, hipStream_t stream)
 {
-    if (n == 0) return MODGPU_OK;
-    if (!dev_buf) return fail(MODGPU_ERR_INVALID, "null device buffer");
-    uint32_t key_res = lcg::key_residue(key);
-    if (key_res == 0) return MODGPU_OK; // keystream is all zero (state sticks at m): identity
-    Plan p = plan_cycle(dev_buf, n, key_res, stream_off, over_pcie, stream);
-    hipError_t e = modgpu_launch_cycle(p.args, p.variant, p.grid, stream);
-    if (e != hipSuccess) {
-        if (p.queue_line >= 0) {
-            QueuePair q;
-            q.line = p.queue_line;
-            q.dev = p.queue_dev;
-            queue_pair_unused(q);
-        }
-        return fail_hip(e, "cycle kernel launch");
-    }
-    g_stats.gpu_launches.fetch_add(1, std::memory_order_relaxed);
-    t_last_launch = {modgpu_variant_kernel_name(p.variant), p.variant, p.grid, modgpu_variant_block(p.variant),
-                     modgpu_variant_chunk_bytes(p.variant), n, p.variant == CYCLE_QUEUE ? p.args.main_groups : p.grid};
-    return MODGPU_OK;
-}
-
-namespace {
-// One launch of the work-queue shape over parts[0..n) (2..kCycleBatchMax non-empty buffers of the current device).
-// Returns MODGPU_OK, an error, or 1: not possible right now (no ticket pair free, a part beyond the jump tables) --
-// the caller launches the parts one by one.
-int launch_batch(void *const *bufs, const uint64_t *sizes, const uint64_t *offs, int n, uint32_t key_res, hipStream_t stream)
-{
-    CycleBatchArgs a{};
-    const uint64_t chunk = modgpu_batch_chunk_bytes();
+    CycleQueueArgs a{};
+    const uint64_t chunk = modgpu_queue_chunk_bytes();
     uint64_t total = 0, bytes = 0;
     for (int k = 0; k < n; ++k) {
-        CycleBatchPart &P = a.part[k];
+        CycleQueuePart &P = a.part[k];
         const uintptr_t addr = reinterpret_cast<uintptr_t>(bufs[k]);
         const uint64_t head = std::min<uint64_t>(sizes[k], (16 - (addr & 15)) & 15);
         const uint64_t words = (sizes[k] - head) / 16;
-        const uint64_t o = (offs ? offs[k] : 0) % lcg::PERIOD;
+        const uint64_t o = (offs ? offs[k] : 0) % lcg::PERIOD; // the stream position of byte j is off + j; positions reduce mod PERIOD
         P.body = static_cast<uint8_t *>(bufs[k]) + head;
         P.head_n = (uint32_t)head;
         P.tail_n = (uint32_t)(sizes[k] - head - words * 16);
+        // chunks sit on absolute chunk-aligned addresses: the first starts `lead` bytes before the body, and the kernel
+        // counts positions from there, so the base state is stepped back by a^(-lead)
         P.lead = (uint32_t)(reinterpret_cast<uintptr_t>(P.body) & (chunk - 1));
         P.end = P.lead + words * 16;
         P.base_head = lcg::state_residue(key_res, o);
         P.base_body = lcg::mulmod(lcg::state_residue(key_res, o + head), lcg::powmod(lcg::A, lcg::PERIOD - P.lead % lcg::PERIOD));
         P.base_tail = lcg::state_residue(key_res, o + head + (words * 16) % lcg::PERIOD);
         const uint64_t n_chunks = (P.end + chunk - 1) / chunk, first = P.lead != 0 ? 1 : 0;
-        if (n_chunks >= (1ull << 24)) return 1; // the kernel's chunk jump tables are three bytes wide
+        if (n_chunks >= (1ull << 24)) return 1;
         a.start[k] = (uint32_t)total;
         total += n_chunks > first ? n_chunks - first : 0; // the cut first chunk is workgroup k's, outside the index space
         bytes += sizes[k];
@@ -535,24 +491,55 @@ int launch_batch(void *const *bufs, const uint64_t *sizes, const uint64_t *offs,
     a.queue = q.pair;
     a.queue_done = q.done;
     a.queue_seq = q.seq;
+    // With chunks handed out by tickets any grid finishes the job, and the memory system does best with fewer
+    // streams than CUs: 25 workgroups per 32 CUs (200 on MI355X) -- measured plateau 184..208, +1.6 % at 4 GiB and
+    // +2.4 % at 402 MiB over one per CU; 160 and below fall off (profiles/r02_tune_cycle_queue_grid.txt).
+    // ... at the clock the chip normally runs at.  While power management holds the shader clock low (the first ~10 ms after
+    // load onset) the kernel is bound by its arithmetic instead, and the CUs left idle are worth more than the tidy memory
+    // pattern: they get a HELPER workgroup each, which measures the clock when it starts and joins the ticket queue only
+    // while it is below MODGPU_HELPER_BELOW_MHZ (default 1850; cycle_kernel_impl.h; profiles/r03_first_pass.txt, r03_tune_dvfs.txt).
     uint64_t cap = 0, helpers = 0;
     queue_grid(total, large_grid(), &cap, &helpers);
     const uint64_t main_groups = std::max<uint64_t>(1, std::min<uint64_t>(total, cap));
     a.main_groups = (uint32_t)main_groups;
     a.helper_below_mhz = helper_mode() == 1 ? 0xFFFFFFFFu : helper_below_mhz();
     const uint32_t grid = (uint32_t)(main_groups + helpers);
-    hipError_t e = modgpu_launch_cycle_batch(a, grid, stream);
+    hipError_t e = modgpu_launch_cycle_queue(a, grid, stream);
     if (e != hipSuccess) {
         queue_pair_unused(q);
-        return fail_hip(e, "cycle batch kernel launch");
+        return fail_hip(e, "cycle kernel launch (work queue)");
     }
     g_stats.gpu_launches.fetch_add(1, std::memory_order_relaxed);
-    g_batch_launches.fetch_add(1, std::memory_order_relaxed);
-    g_batch_parts.fetch_add((uint64_t)n, std::memory_order_relaxed);
-    t_last_launch = {modgpu_batch_kernel_name(), CYCLE_BATCH, grid, modgpu_batch_block(), (uint32_t)chunk, bytes, (uint32_t)main_groups};
+    if (n > 1) {
+        g_batch_launches.fetch_add(1, std::memory_order_relaxed);
+        g_batch_parts.fetch_add((uint64_t)n, std::memory_order_relaxed);
+    }
+    t_last_launch = {modgpu_queue_kernel_name(), n > 1 ? CYCLE_BATCH : CYCLE_QUEUE, grid, modgpu_queue_block(), (uint32_t)chunk, bytes, (uint32_t)main_groups};
     return MODGPU_OK;
 }
+
 } // namespace
+
+int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off, hipStream_t stream, bool over_pcie)
+{
+    if (n == 0) return MODGPU_OK;
+    if (!dev_buf) return fail(MODGPU_ERR_INVALID, "null device buffer");
+    uint32_t key_res = lcg::key_residue(key);
+    if (key_res == 0) return MODGPU_OK; // keystream is all zero (state sticks at m): identity
+    int variant = choose_variant(dev_buf, n, over_pcie);
+    if (variant == CYCLE_QUEUE) {
+        const int rc = launch_queue(&dev_buf, &n, &stream_off, 1, key_res, stream);
+        if (rc != 1) return rc;
+        variant = CYCLE_LARGE; // no ticket pair to be had: the same bursts with the static chunk map
+    }
+    Plan p = plan_cycle(dev_buf, n, key_res, stream_off, over_pcie, variant);
+    hipError_t e = modgpu_launch_cycle(p.args, p.variant, p.grid, stream);
+    if (e != hipSuccess) return fail_hip(e, "cycle kernel launch");
+    g_stats.gpu_launches.fetch_add(1, std::memory_order_relaxed);
+    t_last_launch = {modgpu_variant_kernel_name(p.variant), p.variant, p.grid, modgpu_variant_block(p.variant),
+                     modgpu_variant_chunk_bytes(p.variant), n, p.grid};
+    return MODGPU_OK;
+}
 
 // n_parts buffers resident on the CURRENT device, each its own Cycle call (keystream from offs[i], or 0), asynchronous on
 // `stream`.  Runs of up to kCycleBatchMax non-empty parts share one launch when that pays (profiles/r03_parts_batched.txt,
@@ -583,7 +570,7 @@ int cycle_batch_impl(void *const *bufs, const uint64_t *sizes, const uint64_t *o
         }
         int rc = 1;
         if (g >= 2 && batch_mode() != 2 && (batch_mode() == 1 || bytes >= kLargeMin || bytes <= kBatchSmallMean * (uint64_t)g))
-            rc = launch_batch(gb, gs, go, g, key_res, stream);
+            rc = launch_queue(gb, gs, go, g, key_res, stream);
         if (rc == 1) {
             rc = MODGPU_OK;
             for (int k = 0; k < g && rc == MODGPU_OK; ++k) rc = cycle_device_impl(gb[k], gs[k], key, go[k], stream);

@@ -526,7 +526,7 @@ def test_several_parts_in_one_launch_ragged(gpu_t, oracle, helpers):
         gpu.debug_set_batch(1)
         gpu.cycle_batch_device(ptrs[:16], sizes[:16], 0x90CFC0AB, device=d.device)
         info = gpu.last_launch()
-        assert info["variant"] == 3 and info["kernel"].startswith("modgpu_cycle_batch_kernel<") and info["bytes"] == sum(sizes[:16]), info
+        assert info["variant"] == 3 and info["kernel"].startswith("modgpu_cycle_queue_kernel<") and info["bytes"] == sum(sizes[:16]), info
         gpu.cycle_batch_device(ptrs[16:], sizes[16:], 0x90CFC0AB, device=d.device)
         d.sync()
         assert np.array_equal(d.download(cap), w), ("involution across the two routes", grid)

@@ -45,7 +45,9 @@ template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = 16, int SYNC
 // ALG: 2 = the shipped keystream sequence (canonicalising carry out of the fold, 3 instructions per byte), 1 = round 2's (4 per byte)
 template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int SAUX = 16, int LAUX = 2, int B1 = 1, int B2 = 1, int ALG = 2> void launch_queue(const CycleArgs &a, uint32_t grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, ALG, SAUX, TRACE, DEPTH, MODE, LAUX, B1, B2>), dim3(grid), dim3(BLOCK), 0, st, a);
+    // (the kernel takes a table of parts: one buffer planned as a CycleArgs is a table of one)
+    hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, ALG, SAUX, TRACE, DEPTH, MODE, LAUX, B1, B2>), dim3(grid), dim3(BLOCK), 0, st,
+                       cycle_queue_args_of(a, (uint32_t)U * BLOCK * 16));
 }
 
 // `tune_cycle trace <bytes> [grid]`: where a launch's time goes.  Runs the shipped streaming shape with
