@@ -153,6 +153,12 @@ int modgpu_hdr_encrypt_host(uint8_t *hdr, uint64_t size, int ps4, int device);
 int modgpu_cycle_parts_host(uint8_t *const *parts, const uint64_t *sizes, int n_parts,
                             int32_t key, int n_devices);
 
+/* ONE host buffer over several GPUs: contiguous spans (multiples of 2 MiB, at least 64 MiB each), span d on GPU d with
+ * stream offset stream_off + its position -- jump-ahead makes every span an independent stream, so there is still no
+ * exchange step -- each through its own PCIe link, one host thread per GPU.  n_devices <= 0 means all devices;
+ * a buffer under 128 MiB stays on one GPU.  Result identical to modgpu_cycle_host. */
+int modgpu_cycle_host_split(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, int n_devices);
+
 /* The same for parts that are already resident in HBM, part i on GPU devices[i] (BASELINE config 3: 8 x 4 GiB,
  * one per GPU).  The launches are asynchronous, so the calling thread alone keeps every GPU busy; the call
  * returns when all of them have finished.  No inter-GPU traffic.  Parts that share a GPU go to it through

@@ -33,6 +33,7 @@ EXPORTS = {
     "modgpu_hdr_encrypt_host": (_int, [_vp, _u64, _int, _int]),
     "modgpu_cycle_parts_host": (_int, [ctypes.POINTER(_vp), ctypes.POINTER(_u64), _int, _i32, _int]),
     "modgpu_cycle_parts_device": (_int, [ctypes.POINTER(_vp), ctypes.POINTER(_u64), ctypes.POINTER(_int), _int, _i32]),
+    "modgpu_cycle_host_split": (_int, [_vp, _u64, _i32, _u64, _int]),
     "modgpu_cycle_batch_device": (_int, [ctypes.POINTER(_vp), ctypes.POINTER(_u64), ctypes.POINTER(_u64), _int, _i32, _int, _vp]),
     "modgpu_cycle_file": (_int, [ctypes.c_char_p, ctypes.c_char_p, _i32, _u64, _int]),
     "modgpu_cycle_file_to_host": (_int, [ctypes.c_char_p, _u64, _vp, _u64, _i32, _u64, _int]),
@@ -382,6 +383,12 @@ def cycle_parts_device(buffers, key):
     sizes = (_u64 * n)(*[b.nbytes for b in buffers])
     devs = (_int * n)(*[b.device for b in buffers])
     _check(lib().modgpu_cycle_parts_device(ptrs, sizes, devs, n, as_int32(key)))
+
+
+def cycle_host_split(buf, key, stream_off=0, n_devices=0):
+    """One host buffer over several GPUs: contiguous spans, span d on GPU d with its own stream offset (no exchange step)."""
+    _check(lib().modgpu_cycle_host_split(_host_ptr(buf), buf.size, as_int32(key), stream_off, n_devices))
+    return buf
 
 
 def cycle_batch_device(ptrs, sizes, key, stream_offs=None, device=-1, stream=None):

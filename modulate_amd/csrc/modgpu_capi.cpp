@@ -779,43 +779,75 @@ int modgpu_hdr_encrypt_host(uint8_t *hdr, uint64_t size, int ps4, int device)
     });
 }
 
+// Host buffers spread over the GPUs, buffer i -> GPU i mod N, one host thread per GPU, each buffer its own stream from offs[i]
+// (nullptr: 0).  No inter-GPU traffic.
+static int parts_host_impl(uint8_t *const *parts, const uint64_t *sizes, const uint64_t *offs, int n_parts, int32_t key, int n_devices)
+{
+    int avail = logical_count();
+    if (avail <= 0) return fail(MODGPU_ERR_NO_DEVICE, "no HIP device visible");
+    if (n_devices <= 0 || n_devices > avail) n_devices = avail;
+    n_devices = std::min(n_devices, std::max(n_parts, 1));
+    std::vector<int> rcs((size_t)n_devices, MODGPU_OK);
+    std::vector<std::string> errs((size_t)n_devices);
+    auto body = [&](int d, bool own_thread) {
+        if (own_thread) run_near_device(d); // this worker's copies run on the socket its GPU hangs off
+        for (int i = d; i < n_parts; i += n_devices) { // part i -> GPU i mod N
+            int rc = cycle_host_impl(parts[i], sizes[i], key, offs ? offs[i] : 0, d, nullptr);
+            if (rc) {
+                rcs[d] = rc;
+                errs[d] = t_err;
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> workers;
+    int started = 1; // device 0's parts are done on the calling thread
+    try {
+        for (int d = 1; d < n_devices; ++d, ++started) workers.emplace_back(body, d, true);
+    } catch (...) { // thread limit: the remaining devices' parts are done here, one device after another
+    }
+    body(0, false);
+    for (int d = started; d < n_devices; ++d) body(d, false);
+    for (auto &w : workers) w.join();
+    for (int d = 0; d < n_devices; ++d)
+        if (rcs[d]) {
+            t_err = errs[d];
+            return rcs[d];
+        }
+    return MODGPU_OK;
+}
+
 int modgpu_cycle_parts_host(uint8_t *const *parts, const uint64_t *sizes, int n_parts, int32_t key,
                             int n_devices)
 {
     return guarded([&]() -> int {
         if (n_parts < 0 || (n_parts > 0 && (!parts || !sizes))) return fail(MODGPU_ERR_INVALID, "bad part list");
-        int avail = logical_count();
+        return parts_host_impl(parts, sizes, nullptr, n_parts, key, n_devices);
+    });
+}
+
+// ONE host buffer over several GPUs ("a single buffer can also be split at any byte offset using stream_off" --
+// jump-ahead makes every span an independent stream): contiguous spans, span d on GPU d with stream offset stream_off + its
+// position, each through its own PCIe link.  Spans are whole multiples of 2 MiB and at least 64 MiB, so a small buffer stays
+// on one GPU.
+int modgpu_cycle_host_split(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, int n_devices)
+{
+    return guarded([&]() -> int {
+        if (n && !host_buf) return fail(MODGPU_ERR_INVALID, "null host buffer");
+        const int avail = logical_count();
         if (avail <= 0) return fail(MODGPU_ERR_NO_DEVICE, "no HIP device visible");
         if (n_devices <= 0 || n_devices > avail) n_devices = avail;
-        n_devices = std::min(n_devices, std::max(n_parts, 1));
-        std::vector<int> rcs((size_t)n_devices, MODGPU_OK);
-        std::vector<std::string> errs((size_t)n_devices);
-        auto body = [&](int d, bool own_thread) {
-            if (own_thread) run_near_device(d); // this worker's copies run on the socket its GPU hangs off
-            for (int i = d; i < n_parts; i += n_devices) { // part i -> GPU i mod N
-                int rc = cycle_host_impl(parts[i], sizes[i], key, 0, d, nullptr);
-                if (rc) {
-                    rcs[d] = rc;
-                    errs[d] = t_err;
-                    return;
-                }
-            }
-        };
-        std::vector<std::thread> workers;
-        int started = 1; // device 0's parts are done on the calling thread
-        try {
-            for (int d = 1; d < n_devices; ++d, ++started) workers.emplace_back(body, d, true);
-        } catch (...) { // thread limit: the remaining devices' parts are done here, one device after another
+        constexpr uint64_t kGrain = 2ull << 20, kMinSpan = 64ull << 20;
+        const uint64_t use = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_devices, n / kMinSpan));
+        const uint64_t span = ((n + use - 1) / use + kGrain - 1) / kGrain * kGrain;
+        std::vector<uint8_t *> parts;
+        std::vector<uint64_t> sizes, offs;
+        for (uint64_t at = 0; at < n; at += span) {
+            parts.push_back(host_buf + at);
+            sizes.push_back(std::min<uint64_t>(span, n - at));
+            offs.push_back(stream_off + at); // (wraps at 2^64 like the single-stream call: positions reduce mod PERIOD downstream)
         }
-        body(0, false);
-        for (int d = started; d < n_devices; ++d) body(d, false);
-        for (auto &w : workers) w.join();
-        for (int d = 0; d < n_devices; ++d)
-            if (rcs[d]) {
-                t_err = errs[d];
-                return rcs[d];
-            }
-        return MODGPU_OK;
+        return parts_host_impl(parts.data(), sizes.data(), offs.data(), (int)parts.size(), key, (int)use);
     });
 }
 

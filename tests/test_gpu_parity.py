@@ -872,6 +872,26 @@ for d in range(8):
     b = M.DeviceBuffer(pt.size, device=d); b.upload(pt); b.cycle(M.KEY_PS4); b.sync()
     assert np.array_equal(b.download(), want), d
     b.free()
+# ONE host buffer over all GPUs (SURVEY 8e: split at byte offsets, every span its own stream offset): 8 spans of 2 MiB
+# multiples, pageable and page-locked memory, a stream offset that wraps the period inside a span; small buffers stay whole
+n = (600 << 20) + 12345
+pt = O.splitmix_bytes(n + 8, 31)
+for off in (0, O.PERIOD - (100 << 20) - 3):
+    got = pt.copy()
+    before = M.path_stats()["gpu_calls"]
+    M.cycle_host_split(got[5:5 + n], M.KEY_PS3, off, 0)
+    assert M.path_stats()["gpu_calls"] - before == 8                 # 600 MiB / 8 -> spans of 76 MiB
+    w = pt.copy(); O.cycle_at(w[5:5 + n], O.KEY_PS3, off)
+    assert np.array_equal(got, w), off
+pb = M.PinnedBuffer(n)
+pb.array[:] = pt[:n]
+M.cycle_host_split(pb.array, M.KEY_PS4, 7, 3)                        # three devices: spans of 200 MiB + the rest
+assert np.array_equal(pb.array, O.cycle_at(pt[:n].copy(), O.KEY_PS4, 7))
+pb.free()
+small = O.splitmix_bytes((100 << 20) + 1, 9)
+before = M.path_stats()["gpu_calls"]
+assert np.array_equal(M.cycle_host_split(small.copy(), M.KEY_PS4, 0, 8), O.cycle(small.copy(), O.KEY_PS4))
+assert M.path_stats()["gpu_calls"] - before == 1                     # under 128 MiB: one GPU
 # BASELINE config 3 proper: parts RESIDENT in HBM, part i on (logical) GPU i, one call drives all of them
 sizes = [(300 << 20) + 16 * i for i in range(8)]
 bufs = [M.DeviceBuffer(s, device=i) for i, s in enumerate(sizes)]
