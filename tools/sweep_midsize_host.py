@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Pageable host buffers of 16-256 MiB through modgpu_cycle_host (staged route: memcpy -> pinned slot -> kernel over PCIe ->
+memcpy back) by slot size and pipeline count -- one child process per setting (the tunables are latched at load).
+
+    python tools/sweep_midsize_host.py
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r"""
+import sys, time, numpy as np
+sys.path.insert(0, %r)
+import modulate_amd as M
+out = []
+for mib in (16, 32, 64, 128, 256):
+    n = mib << 20
+    buf = np.random.default_rng(1).integers(0, 256, size=n, dtype=np.uint8)
+    best = 1e9
+    for _ in range(6):
+        t0 = time.perf_counter(); M.cycle_host(buf, M.KEY_PS4); best = min(best, time.perf_counter() - t0)
+    out.append("%%6.2f ms %%5.1f GB/s" %% (best * 1e3, n / best / 1e9))
+print(" | ".join(out))
+"""
+print("%-34s | " % "setting" + " | ".join("%3d MiB            " % m for m in (16, 32, 64, 128, 256)))
+for chunk in (None, 1, 2, 4):
+    for pipes in (8, 16):
+        env = dict(os.environ, MODGPU_REQUIRE_GPU="1", MODGPU_HOST_PIPES=str(pipes))
+        if chunk:
+            env["MODGPU_HOST_CHUNK_MB"] = str(chunk)
+        r = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, env=env, timeout=600)
+        print("%-34s | %s" % ("slot <= %s MiB, %2d pipelines" % (chunk or "8 (default)", pipes), r.stdout.strip() or r.stderr[-300:]), flush=True)
