@@ -842,10 +842,11 @@ int modgpu_cycle_host_split(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t
         const uint64_t span = ((n + use - 1) / use + kGrain - 1) / kGrain * kGrain;
         std::vector<uint8_t *> parts;
         std::vector<uint64_t> sizes, offs;
+        const uint64_t base = stream_off % lcg::PERIOD; // reduced first: stream_off + position must not wrap at 2^64
         for (uint64_t at = 0; at < n; at += span) {
             parts.push_back(host_buf + at);
             sizes.push_back(std::min<uint64_t>(span, n - at));
-            offs.push_back(stream_off + at); // (wraps at 2^64 like the single-stream call: positions reduce mod PERIOD downstream)
+            offs.push_back(base + at);
         }
         return parts_host_impl(parts.data(), sizes.data(), offs.data(), (int)parts.size(), key, (int)use);
     });

@@ -876,7 +876,7 @@ for d in range(8):
 # multiples, pageable and page-locked memory, a stream offset that wraps the period inside a span; small buffers stay whole
 n = (600 << 20) + 12345
 pt = O.splitmix_bytes(n + 8, 31)
-for off in (0, O.PERIOD - (100 << 20) - 3):
+for off in (0, O.PERIOD - (100 << 20) - 3, (1 << 64) - (300 << 20)):     # (the last: stream_off + position passes 2^64)
     got = pt.copy()
     before = M.path_stats()["gpu_calls"]
     M.cycle_host_split(got[5:5 + n], M.KEY_PS3, off, 0)
