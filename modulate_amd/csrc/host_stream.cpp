@@ -234,6 +234,9 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
 {
     if (touched) *touched = false;
     if (n == 0) return MODGPU_OK;
+    // byte j is at stream position stream_off + j, taken in the integers and reduced mod the generator's period: reduce the
+    // offset first, so that adding a chunk's position below can never wrap at 2^64 (which is not a multiple of the period)
+    stream_off %= 0x7FFFFFFEull;
     int dev = 0;
     DeviceScope scope(device); // the calling thread gets its own current device back
     int rc = scope.rc ? scope.rc : resolve_device(device, &dev);

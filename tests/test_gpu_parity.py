@@ -151,6 +151,19 @@ def test_stream_offsets(gpu, oracle):
             assert np.array_equal(got, oracle.keystream(key, n, off)), (hex(key), off)
 
 
+def test_stream_offset_near_2_to_64_on_the_chunked_routes(gpu, oracle):
+    """Byte j sits at stream position stream_off + j in the integers (the keystream is periodic, 2^64 is not a multiple of its
+    period): a buffer that is staged in several chunks, or split over devices, must not wrap the sum at 2^64."""
+    n, off = (21 << 20) + 5, (1 << 64) - 70000
+    want = oracle.keystream(0xC64EED30, n, off)
+    assert np.array_equal(gpu.cycle_host(np.zeros(n, np.uint8), 0xC64EED30, stream_off=off), want)     # pageable: 4 MiB slots
+    pb = gpu.PinnedBuffer(n)
+    pb.array[:] = 0
+    gpu.cycle_host(pb.array, 0xC64EED30, stream_off=off)                                                # page-locked: in place
+    assert np.array_equal(pb.array, want)
+    pb.free()
+
+
 def test_split_stream_equals_one_call(gpu, oracle):
     """One logical stream cut at arbitrary byte offsets == a single Cycle."""
     n = 3_000_017
