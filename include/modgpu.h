@@ -100,7 +100,9 @@ const char *modgpu_last_error(void);
  * Allocation-free and capturable into a hipGraph.  Any number of launches may be in flight at once, on any
  * streams, eager or replayed from graphs: the scheduling scratch of a large launch is never shared between two
  * launches that could overlap (a captured launch owns its scratch for good; an eager one gets scratch whose
- * previous user has finished, or a launch shape that needs none). */
+ * previous user has finished, or a launch shape that needs none).  The one thing to avoid: two EXECUTABLE graphs
+ * instantiated from the same capture and launched at the same time -- they replay the same node, scratch included
+ * (one executable graph never overlaps itself; capture again for a second concurrent user). */
 int modgpu_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off,
                         int device, void *hip_stream);
 
