@@ -109,6 +109,23 @@ def test_gpu_entry_points_fail_loudly_without_gpu(modgpu):
     assert st["gpu_calls"] == 0 and st["gpu_launches"] == 0
 
 
+def test_missing_extension_fails_loudly(tmp_path):
+    """No library, no result: the Python layer has no arithmetic of its own to fall back to (the oracle is never imported
+    by the package), so a missing libmodgpu.so is an error at the first call."""
+    code = ("import numpy as np, modulate_amd as M\n"
+            "try:\n"
+            "    M.cycle_auto_host(np.zeros(64, np.uint8), M.KEY_PS4)\n"
+            "except M.ModGpuError as e:\n"
+            "    print('LOUD', e.code, 'not built' in str(e))\n")
+    e = dict(os.environ, PYTHONPATH=ROOT, MODGPU_LIB=str(tmp_path / "no_such_libmodgpu.so"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=120)
+    assert r.returncode == 0 and "LOUD -1 True" in r.stdout, r.stdout + r.stderr[-1500:]
+    for name in os.listdir(os.path.join(ROOT, "modulate_amd")):  # and the package never reaches into oracle/
+        if name.endswith(".py"):
+            src = open(os.path.join(ROOT, "modulate_amd", name)).read()
+            assert "import oracle" not in src and "from oracle" not in src, name
+
+
 def test_argument_errors(modgpu):
     bad = np.zeros(64, np.uint8)
     with pytest.raises(modgpu.ModGpuError) as e:
