@@ -287,6 +287,33 @@ def test_beyond_4gib_offsets_device(gpu, oracle):
     dbuf.free()
 
 
+def test_48gib_in_one_call_device(gpu, oracle):
+    """Sized for the card (288 GB of HBM): ONE call over 48 GiB + 12 345 bytes -- 786 000 chunks, so the top byte of the kernel's
+    three-byte chunk jump (a^(65536 * c), c >> 16 up to 11) is exercised well past what a 4 GiB part reaches.  Nothing is
+    uploaded: whatever the fresh allocation holds is the plaintext, and  before ^ after  must be the keystream on windows across
+    the buffer (each 4 GiB boundary, the period's multiples, the ragged end); a second pass must give every window back."""
+    n = (48 << 30) + 12_345
+    base, so, key = 4, (1 << 40) + 99, 0xC64EED30
+    dbuf = gpu.DeviceBuffer(n + 64)
+    P = oracle.PERIOD
+    wins = sorted({0, n - (1 << 20), n // 2 + 7, 3 * P - 4096, 17 * P - 4096} | {(k << 32) - (1 << 16) for k in range(1, 13)})
+    before = {off: dbuf.download(min(1 << 20, n - off), offset=base + off) for off in wins}
+    guards = (dbuf.download(4, 0), dbuf.download(60, base + n))
+    dbuf.cycle(key, n=n, offset=base, stream_off=so)
+    dbuf.sync()
+    info = gpu.last_launch()
+    assert info["variant"] == 2 and info["bytes"] == n, info
+    for off in wins:
+        ln = before[off].size
+        assert np.array_equal(dbuf.download(ln, offset=base + off) ^ before[off], oracle.keystream(key, ln, so + off)), off
+    dbuf.cycle(key, n=n, offset=base, stream_off=so)
+    dbuf.sync()
+    for off in wins:
+        assert np.array_equal(dbuf.download(before[off].size, offset=base + off), before[off]), off
+    assert np.array_equal(dbuf.download(4, 0), guards[0]) and np.array_equal(dbuf.download(60, base + n), guards[1])
+    dbuf.free()
+
+
 def test_config2_4gib_part_roundtrip(gpu, oracle, golden):
     """BASELINE config 2: one 2^32-byte part on one MI355X, encrypt then decrypt.
     Pass 1 is checked against the oracle on windows + the reference's own 2^32-1 byte golden
