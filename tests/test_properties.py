@@ -1,6 +1,7 @@
 """Property-based checks (hypothesis), CPU only: the product's host loop against the oracle over random keys,
 lengths, alignments and 64-bit stream offsets; the algebra the GPU path relies on (involution, a stream cut at any
-byte equals one call, periodicity); and the C++ header writer against the Python restatement on random tables."""
+byte equals one call, periodicity); the C++ header writer against the Python restatement on random tables; the C++ DTA
+tree reader and writer against theirs on random trees."""
 import os
 
 import numpy as np
@@ -108,3 +109,43 @@ def test_header_writer_equals_restatement_on_random_tables(names, data):
         a.close()
     finally:
         H.select_platform(True)
+
+
+# ---- binary DTA tree: C++ reader + writer against the restatement on random trees ----------------------
+_leaf = st.one_of(
+    st.tuples(st.just("int"), st.sampled_from([0, 6, 8, 9]), st.integers(-(1 << 31), (1 << 31) - 1)),
+    st.tuples(st.just("float"), st.just(1), st.integers(0, (1 << 32) - 1)),
+    st.tuples(st.just("str"), st.sampled_from([5, 18, 33, 35]),
+              st.text(alphabet=st.characters(min_codepoint=1, max_codepoint=255), max_size=40)))  # latin-1, no NUL (C strings upstream)
+
+
+def _tree(children):
+    return st.tuples(st.just("tree"), st.sampled_from([16, 17]), st.integers(-(1 << 15), (1 << 15) - 1),
+                     st.lists(children, min_size=1, max_size=6))
+
+
+_node = st.recursive(_leaf, _tree, max_leaves=40)
+
+
+@settings(max_examples=120, **COMMON)
+@given(top=st.lists(_tree(_node), min_size=1, max_size=4))
+def test_dta_reader_and_writer_equal_restatement_on_random_trees(top):
+    """Typed node trees of any shape (CDtaFile.cpp:57-100, 393-509 load; 362-391, 1302-1326 save): the C++ parse of the
+    restatement's image dumps node for node like the restatement's own tree, and the C++ writer reproduces the image
+    byte for byte -- several top-level trees in the form Load reads (separators), which Save writes only with the quirk fix."""
+    from modulate_amd import host as H
+    from oracle import dta_tree as DT
+    top = [(t[0], 16 if k == 0 else t[1], t[2], t[3]) for k, t in enumerate(top)]  # the first top-level tree is type 16 by construction (CDtaFile.cpp:57-60)
+    blob = DT.serialise(top)
+    assert DT.parse(blob) == top
+    H.lib()
+    H.set_fix_quirks(True)
+    try:
+        out, dump = H.dta_roundtrip(blob)
+    finally:
+        H.set_fix_quirks(False)
+    assert dump == DT.dump(top)
+    assert out == blob
+    if len(top) == 1:  # one top-level tree: the reference's own Save form is the same image
+        out2, _ = H.dta_roundtrip(blob)
+        assert out2 == blob
