@@ -1,7 +1,7 @@
 """Property-based checks (hypothesis), CPU only: the product's host loop against the oracle over random keys,
 lengths, alignments and 64-bit stream offsets; the algebra the GPU path relies on (involution, a stream cut at any
 byte equals one call, periodicity); the C++ header writer against the Python restatement on random tables; the C++ DTA
-tree reader and writer against theirs on random trees."""
+tree reader and writer against theirs on random trees; pack -> save -> load -> extract on random tables."""
 import os
 
 import numpy as np
@@ -149,3 +149,52 @@ def test_dta_reader_and_writer_equal_restatement_on_random_trees(top):
     if len(top) == 1:  # one top-level tree: the reference's own Save form is the same image
         out2, _ = H.dta_roundtrip(blob)
         assert out2 == blob
+
+
+# ---- pack -> save -> load -> extract on random tables, with and without the part cipher ---------------
+# (directories in upper case, file names in lower case: no name is both a file and a directory of another entry)
+fs_names = st.lists(st.tuples(st.lists(st.text(alphabet="ABC", min_size=1, max_size=3), max_size=3), st.text(alphabet="abc019_", min_size=1, max_size=12))
+                    .map(lambda t: "/".join(t[0] + [t[1]])), min_size=1, max_size=40, unique=True)
+
+
+@needs_host_loop
+@settings(max_examples=40, **COMMON)
+@given(names=fs_names, data=st.data())
+def test_pack_save_load_extract_on_random_tables(names, data):
+    """Entry table -> part buffers -> header + part files on disk -> Load -> LoadArkData -> ExtractFiles: every file comes back
+    byte for byte, whatever the split into parts, on both platforms, with the parts stored plain (the reference) or cycled."""
+    import tempfile
+    from modulate_amd import host as H
+    H.lib()
+    H.set_flags(overwrite=True, ignore_new=True, pack_all=False, verbose=False)
+    sizes = [data.draw(st.integers(0, 3000)) for _ in names]
+    n_arks = data.draw(st.integers(1, 4))
+    ps4 = data.draw(st.booleans())
+    from modulate_amd import capi
+    crypt = data.draw(st.booleans()) and capi.device_count() > 0  # (the part cipher is the GPU's: it fails loudly without one)
+    seed = data.draw(st.integers(0, 1 << 30))
+    payload = np.random.default_rng(seed).integers(0, 256, size=sum(sizes), dtype=np.uint8)
+    plat = "ps4" if ps4 else "ps3"
+    H.select_platform(ps4)
+    H.set_fix_quirks(True)  # (SaveArk without a placeholder header in the working directory; ExtractFiles honours its range)
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            a = H.Ark()
+            a.construct_from_table(names, sizes, n_arks, f"main_{plat}")
+            a.build_from_memory(payload)
+            a.enable_part_cipher(crypt)
+            os.makedirs(d + "/packed")
+            a.save(d + "/packed/", f"main_{plat}.hdr")
+            table = {f["name"]: (f["offset"], f["size"]) for f in a.files()}
+            a.close()
+            b = H.Ark().load(d + f"/packed/main_{plat}.hdr")
+            b.enable_part_cipher(crypt)
+            b.load_data()
+            b.extract(d + "/out/")
+            b.close()
+            for nm, (off, size) in table.items():
+                got = np.fromfile(d + "/out/" + nm, dtype=np.uint8) if size else np.zeros(0, np.uint8)
+                assert np.array_equal(got, payload[off:off + size]), nm
+    finally:
+        H.set_fix_quirks(False)
+        H.select_platform(True)
