@@ -387,3 +387,51 @@ def test_integration_binding_compiles_against_the_upstream_header(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     strict = os.environ.get("MODGPU_REQUIRE_GPU", "0") not in ("", "0")
     assert (r.returncode == 0 and "UPSTREAM_BINDING_OK" in r.stdout) or strict, r.stdout + r.stderr
+
+
+def test_parsers_survive_mutated_images(host):
+    """Header and DTA images with random byte flips and truncations: the C++ readers either accept the image or return
+    an error -- never read out of bounds (this test is part of the ASan + UBSan job, tests/test_sanitizers.py)."""
+    from oracle import dta_tree as DT
+    rng = np.random.default_rng(20261004)
+    names = [f"dir{k % 5}/f{k}.bin" for k in range(40)]
+    sizes = [int(x) for x in rng.integers(0, 3000, size=40)]
+    a = host.Ark()
+    a.construct_from_table(names, sizes, 3, "main_ps4")
+    a.build_from_memory(np.zeros(sum(sizes), np.uint8))
+    plain = a.serialise_header(encrypt=False).copy()
+    a.close()
+    dta = bytearray(DT.serialise(DT.synth_tree(rng, 1500) + [("tree", 17, 9, [("int", 0, 5), ("str", 5, "abc")])]))
+    verdicts = {"hdr_ok": 0, "hdr_rejected": 0, "dta_ok": 0, "dta_rejected": 0}
+    try:
+        for it in range(1500):
+            m = plain.copy()
+            for _ in range(int(rng.integers(1, 6))):
+                m[int(rng.integers(4, m.size))] = rng.integers(0, 256)
+            if rng.random() < 0.2:
+                m = m[:int(rng.integers(4, m.size))].copy()
+            body = m[4:]
+            if body.size:
+                host.cycle_via_class(body, 0x90CFC0AB)  # encrypt the mutated plaintext through the product (what Load will undo)
+            b = host.Ark()
+            try:
+                b.parse_header(m)
+                b.files(), b.ark_sizes(), b.ark_paths()
+                verdicts["hdr_ok"] += 1
+            except host.HostError:
+                verdicts["hdr_rejected"] += 1
+            b.close()
+            d = bytearray(dta)
+            for _ in range(int(rng.integers(1, 5))):
+                d[int(rng.integers(0, len(d)))] = int(rng.integers(0, 256))
+            if rng.random() < 0.2:
+                d = d[:int(rng.integers(0, len(d)))]
+            host.set_fix_quirks(bool(it & 1))
+            try:
+                host.dta_roundtrip(bytes(d))
+                verdicts["dta_ok"] += 1
+            except host.HostError:
+                verdicts["dta_rejected"] += 1
+    finally:
+        host.set_fix_quirks(False)
+    assert verdicts["hdr_ok"] > 100 and verdicts["hdr_rejected"] > 100 and verdicts["dta_ok"] > 50 and verdicts["dta_rejected"] > 100, verdicts

@@ -27,7 +27,7 @@ def test_host_logic_under_asan_ubsan():
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
                MODULATE_HOST_LIB=os.path.join(ROOT, "modulate_amd", "_san", "libmodulate_host.so"))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_host_cpu.py"), "-x", "-q",
-                        "-k", "header_writer or straddle or bad_arguments or config1 or framing_without_gpu or quirk or dta", "-p", "no:cacheprovider"],
+                        "-k", "header_writer or straddle or bad_arguments or config1 or framing_without_gpu or quirk or dta or mutated", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "passed" in r.stdout
