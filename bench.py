@@ -223,6 +223,10 @@ def main():
                       "slowest_of_launches_1_to_12": rate(n, max(series)),
                       "cause_of_the_dip": "shader-clock (DVFS) transient after load onset, not the buffer's state: profiles/r03_first_pass.txt"}
 
+    # The first collective of a process group sets the communicator up (seconds, GPU idle).  Do that here, not in the
+    # barrier in front of the timed region: the chip would come to the timed launches from idleness, i.e. straight into
+    # its clock transient (profiles/r03_first_pass.txt), which the warm-up exists to get out of the way.
+    barrier()
     # warmup
     for _ in range(a.warmup):
         part.cycle(a.key)
