@@ -528,6 +528,32 @@ def test_helper_workgroups_of_the_queue_shape(gpu_t, oracle, mode):
         d.free()
 
 
+_HELPER_ENV_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import modulate_amd as M
+from oracle import oracle as O
+n = (300 << 20) + 4099
+pt = O.splitmix_bytes(n + 32, 5)
+d = M.DeviceBuffer(n + 32); d.upload(pt)
+d.cycle(M.KEY_PS3, n=n, offset=7, stream_off=123); d.sync()
+info = M.last_launch()
+assert info["variant"] == 2 and info["grid"] == 256 and info["main_groups"] == 200, info
+w = pt.copy(); O.cycle_at(w[7:7 + n], O.KEY_PS3, 123)
+assert np.array_equal(d.download(), w)
+print("HELPER_ENV_OK")
+"""
+
+
+@pytest.mark.parametrize("mhz", ["0", "99999"], ids=["never_join", "always_join"])
+def test_helper_threshold_from_the_environment(gpu, mhz):
+    """MODGPU_HELPER_BELOW_MHZ as the shipped library latches it: 0 = the helper workgroups never join, a value above any
+    clock = they always do; either way the bytes are the oracle's."""
+    e = dict(os.environ, MODGPU_HELPER_BELOW_MHZ=mhz)
+    r = subprocess.run([sys.executable, "-c", _HELPER_ENV_CHILD % ROOT], capture_output=True, text=True, env=e, timeout=600)
+    assert r.returncode == 0 and "HELPER_ENV_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 @pytest.mark.parametrize("helpers", [2, 1], ids=["no_helpers", "helpers_join"])
 def test_several_parts_in_one_launch_ragged(gpu_t, oracle, helpers):
     """modgpu_cycle_batch_device, forced to batch whatever the sizes: parts that are empty, edge-only, inside the cut first
