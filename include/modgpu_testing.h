@@ -31,7 +31,7 @@ int modgpu_time_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t st
 /* The launch the calling thread made last (any entry point), as the library planned it. */
 typedef struct modgpu_launch_info {
     const char *kernel;   /* the instantiation's name as rocprofv3 prints it, e.g.
-                             "modgpu_cycle_queue_kernel<4, 1024, 1, 18, 0, 1, 0, 2, 1, 1>"; static storage */
+                             "modgpu_cycle_queue_kernel<4, 1024>"; static storage */
     int variant;          /* 0 = small shape, 1 = streaming shape (static chunk map), 2 = streaming shape fed by the work queue,
                              3 = the work-queue shape over several parts in one launch (modgpu_cycle_batch_device; `bytes` = all of them) */
     uint32_t grid;        /* workgroups launched                                                  */

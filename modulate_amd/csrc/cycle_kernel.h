@@ -18,11 +18,6 @@ struct CycleArgs {
                          // addresses, so the first one starts `lead` bytes before the body and is masked there
     uint32_t base_head;  // state of the buffer's first byte
     uint32_t base_tail;  // state of the first tail byte
-    // tools/ only (the product plans a work-queue launch as a CycleQueueArgs directly): one buffer described this way is
-    // turned into a table of one part by cycle_queue_args_of() below
-    uint32_t *queue, *queue_done;
-    uint32_t queue_seq, main_groups, helper_below_mhz;
-    uint64_t *trace;     // nullptr in the product (TRACE instantiations of tools/tune_cycle)
 };
 
 // ---- the work-queue shape: ONE launch over one or several buffers ---------------------------------------------------
@@ -50,41 +45,12 @@ struct CycleQueueArgs {
                                // leave at once.  0 main_groups = every workgroup is a main one.
     uint32_t n_parts;                   // 1 .. kCycleBatchMax
     uint32_t start[kCycleBatchMax + 1]; // first global chunk index of each part; start[n_parts] = total; unused entries = total
-    uint64_t *trace;     // nullptr in the product.  tools/tune_cycle's TRACE instantiation writes per-workgroup
-                         // timestamps here (wall_clock64, 100 MHz): [blk*32+0] start, [+1+k] end of trip k, [+31] XCC id
     CycleQueuePart part[kCycleBatchMax];
 };
 uint32_t modgpu_queue_chunk_bytes();
 uint32_t modgpu_queue_block();
 const char *modgpu_queue_kernel_name();
 hipError_t modgpu_launch_cycle_queue(const CycleQueueArgs &a, uint32_t grid, hipStream_t stream);
-
-// One buffer planned as a CycleArgs (chunk-aligned lead already folded into base_body) as the work-queue kernel's table
-// of one part.  chunk = the instantiation's bytes per workgroup trip.
-inline CycleQueueArgs cycle_queue_args_of(const CycleArgs &a, uint32_t chunk)
-{
-    CycleQueueArgs q{};
-    q.queue = a.queue;
-    q.queue_done = a.queue_done;
-    q.queue_seq = a.queue_seq;
-    q.main_groups = a.main_groups;
-    q.helper_below_mhz = a.helper_below_mhz;
-    q.trace = a.trace;
-    q.n_parts = 1;
-    CycleQueuePart &P = q.part[0];
-    P.body = static_cast<uint8_t *>(a.body);
-    P.lead = a.lead;
-    P.end = (uint64_t)a.lead + a.body_words * 16;
-    P.base_body = a.base_body;
-    P.base_head = a.base_head;
-    P.base_tail = a.base_tail;
-    P.head_n = a.head_n;
-    P.tail_n = a.tail_n;
-    const uint64_t n_chunks = (P.end + chunk - 1) / chunk, first = a.lead != 0 ? 1 : 0;
-    const uint32_t total = (uint32_t)(n_chunks > first ? n_chunks - first : 0);
-    for (int k = 1; k <= kCycleBatchMax; ++k) q.start[k] = total;
-    return q;
-}
 
 // Launch shapes.  A workgroup trip covers `chunk_bytes` contiguous bytes; the grid strides over
 // chunks.  grid * chunk_bytes / 4096 must stay <= 65536 (two-level tile jump table).
@@ -97,9 +63,9 @@ enum CycleVariant : int {
 constexpr int kCycleVariants = 3;
 uint32_t modgpu_variant_chunk_bytes(int variant);
 uint32_t modgpu_variant_block(int variant);
-// The instantiation's name as a profiler prints it ("modgpu_cycle_kernel<8, 1024, 1, 2, 0, 16, 3>"),
+// The instantiation's name as a profiler prints it ("modgpu_cycle_kernel<8, 1024, 2, true>"),
 // generated from the same template arguments the launch uses, so it cannot go stale.
 const char *modgpu_variant_kernel_name(int variant);
 
-// Returns hipGetLastError().
+// CYCLE_SMALL or CYCLE_LARGE (the work-queue shape takes a table: modgpu_launch_cycle_queue).  Returns hipGetLastError().
 hipError_t modgpu_launch_cycle(const CycleArgs &a, int variant, uint32_t grid, hipStream_t stream);

@@ -13,7 +13,7 @@
 // Integer only: this is HBM-bound byte work, no MFMA; LDS holds nothing but an 8-byte ticket mailbox.  One byte costs
 // two v_mad_u64_u32 (the product, then the Mersenne fold 2^31 == 1 mod m as a second multiply-add, whose carry-out IS
 // the canonicalising +1) and one SDWA add-with-carry that packs it: 20 issue cycles; "^0xFF" and the data XOR are one
-// v_xnor per dword.  (ALG 2 in cycle_kernel_impl.h; ALG 1, one instruction more per byte, stays for A/B in tools/.)
+// v_xnor per dword.  (ALG 2 in cycle_kernel_impl.h; the small shape keeps ALG 1, one instruction more per byte.)
 //
 // Three launch shapes (cycle_kernel.h):
 //   queue   what the roofline is measured on (buffers > 256 MiB): persistent 1024-thread workgroups, 25 per 32 CUs,
@@ -38,49 +38,46 @@
 
 namespace {
 // One launch shape = one instantiation; everything the host layer asks about a shape comes from here.
-template <int U, int BLOCK, int ALG, int PIPE, int SAUX, int SYNC> struct Shape {
+template <int U, int BLOCK, int ALG, bool STREAM> struct Shape {
     static constexpr uint32_t chunk = (uint32_t)U * BLOCK * lcg::WORD;
     static constexpr uint32_t block = BLOCK;
     static void launch(const CycleArgs &a, uint32_t grid, hipStream_t stream)
     {
-        hipLaunchKernelGGL((modgpu_cycle_kernel<U, BLOCK, ALG, PIPE, MODE_FULL, SAUX, SYNC>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((modgpu_cycle_kernel<U, BLOCK, ALG, STREAM>), dim3(grid), dim3(BLOCK), 0, stream, a);
     }
-    static const char *name()
+    static const char *name() // as a profiler prints it
     {
         static char buf[96];
-        static const int n = std::snprintf(buf, sizeof buf, "modgpu_cycle_kernel<%d, %d, %d, %d, %d, %d, %d>", U, BLOCK, ALG, PIPE, (int)MODE_FULL, SAUX, SYNC);
+        static const int n = std::snprintf(buf, sizeof buf, "modgpu_cycle_kernel<%d, %d, %d, %s>", U, BLOCK, ALG, STREAM ? "true" : "false");
         (void)n;
         return buf;
     }
 };
 // the streaming shape fed from a ticket counter instead of the static chunk map
-template <int U, int BLOCK, int ALG, int SAUX> struct QueueShape {
+template <int U, int BLOCK> struct QueueShape {
     static constexpr uint32_t chunk = (uint32_t)U * BLOCK * lcg::WORD;
     static constexpr uint32_t block = BLOCK;
-    // product settings of the tuning-only template arguments: TRACE 0, DEPTH 1, MODE_FULL, nt loads, both
-    // workgroup barriers (B1 in front of the load burst, B2 in front of the store burst)
     static void launch(const CycleQueueArgs &a, uint32_t grid, hipStream_t stream)
     {
-        hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK, ALG, SAUX, 0, 1, MODE_FULL, AUX_NT, 1, 1>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK>), dim3(grid), dim3(BLOCK), 0, stream, a);
     }
     static const char *name()
     {
-        static char buf[128];
-        static const int n = std::snprintf(buf, sizeof buf, "modgpu_cycle_queue_kernel<%d, %d, %d, %d, 0, 1, %d, %d, 1, 1>", U, BLOCK, ALG, SAUX,
-                                           (int)MODE_FULL, (int)AUX_NT);
+        static char buf[96];
+        static const int n = std::snprintf(buf, sizeof buf, "modgpu_cycle_queue_kernel<%d, %d>", U, BLOCK);
         (void)n;
         return buf;
     }
 };
-// one word per thread, 256 threads, no pipeline: launch-latency-bound sizes
-using Small = Shape<1, 256, 1, 0, AUX_SC1, 0>; // (latency-bound sizes: the 4-instruction sequence, whose register footprint keeps 8 waves per SIMD)
-// U=8 words x 1024 threads, SDWA keystream, pipelined + loads-first, sc1 stores, workgroup-synchronous bursts
-using Large = Shape<8, 1024, 2, 2, AUX_SC1, 3>;
+// one word per thread, 256 threads, no pipeline: launch-latency-bound sizes (the 4-instruction keystream sequence)
+using Small = Shape<1, 256, 1, false>;
+// U=8 words x 1024 threads, three-instruction keystream, pipelined + loads-first, sc1 stores, workgroup-synchronous bursts
+using Large = Shape<8, 1024, 2, true>;
 // 1024 threads x 4 words = 64 KiB chunks: measured best under the queue (profiles/r02_tune_cycle_queue_shapes.txt,
 // every row validated): 128 KiB chunks balance coarser, 32 KiB and below saturate the ticket counter (~80 tickets/us
 // chip-wide), 512-thread workgroups and a second chunk of loads in flight lose 1 %; stores sc1+nt gain 0.5-1.8 %
 // over sc1 alone at every size
-using Queue = QueueShape<4, 1024, 2, AUX_SC1 | AUX_NT>;
+using Queue = QueueShape<4, 1024>;
 } // namespace
 
 uint32_t modgpu_queue_chunk_bytes() { return Queue::chunk; }
@@ -107,8 +104,7 @@ const char *modgpu_variant_kernel_name(int variant)
 
 hipError_t modgpu_launch_cycle(const CycleArgs &a, int variant, uint32_t grid, hipStream_t stream)
 {
-    if (variant == CYCLE_QUEUE) Queue::launch(cycle_queue_args_of(a, Queue::chunk), grid, stream); // (tools; the product plans a table itself)
-    else if (variant == CYCLE_LARGE) Large::launch(a, grid, stream);
+    if (variant == CYCLE_LARGE) Large::launch(a, grid, stream);
     else Small::launch(a, grid, stream);
     return hipGetLastError();
 }

@@ -1,6 +1,8 @@
-// cycle_kernel_impl.h -- device code of the cycle kernel (see cycle_kernel.hip for the design
-// notes).  Kept in a header so tools/tune_cycle.hip can instantiate and time exactly the code the
-// product ships, next to copy-only / compute-only ablations of it.
+// cycle_kernel_impl.h -- device code of the cycle kernels (see cycle_kernel.hip for the design notes): the arithmetic,
+// and the launch shapes the product ships -- nothing else.  Kept in a header so tools/ can instantiate and time exactly
+// this code; every timing ablation, trace hook and rejected variant (copy-only / compute-only loops, the LDS stage,
+// other pipeline depths and barrier placements, the plain-C keystream) lives in tools/cycle_kernel_lab.h, which
+// includes this file and cannot change it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -49,9 +51,9 @@ __device__ __forceinline__ uint32_t mulmod_canon(uint32_t x, uint32_t y)
 }
 
 // ---- keystream bytes of one dword --------------------------------------------------------
-// ALG 0: plain C; the compiler packs the four low bytes with shifts / v_perm.
-// ALG 1: canonicalise and pack in one SDWA add per byte: byte J of `w` := low8(X + (X >> 31)).
+// ALG 1: canonicalise and pack in one SDWA add per byte: byte J of `w` := low8(X + (X >> 31)).   (small shape)
 // ALG 2: as 1, with the "+ (X >> 31)" taken from the fold's carry-out (ks_word_carry, one block per word): no shift.
+//        (streaming shapes)
 template <int SEL> __device__ __forceinline__ void put_byte(uint32_t &w, uint32_t X)
 {
     uint32_t c = X >> 31; // the only possible excess over the canonical residue is m: +1 mod 256
@@ -94,6 +96,10 @@ template <int J> __device__ __forceinline__ uint32_t state_x(uint32_t s)
 //   * gfx9 VOP3 reads one scalar operand per instruction: the multiplier is the scalar, bias pair and zero live in VGPRs;
 //   * gfx940+: a VALU write of VCC needs 2 wait states before a VALU reads it as carry-in (the compiler inserts s_nop 1
 //     there): the product of the byte after next, plus one s_nop 0, sit between each fold and its addc.
+//   * gfx940+: a VALU that writes part of a VGPR (SDWA dst_sel) needs 1 wait state before a VALU reads that VGPR (LLVM:
+//     hasDstSelForwardingHazard).  Inside the block three instructions sit between two addc's of one dword; the block ENDS
+//     with an s_nop 0, because the next instruction is the compiler's (typically the v_xnor on w[3]) and its hazard
+//     recognizer cannot see what the block's last instruction was.
 // w[0] comes in holding the lane state s (byte 0 of the word is the state itself), w[1..3] are written whole.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm" // "clobber list contains reserved registers: s94, s95" -- reserved by us, for this
@@ -127,6 +133,7 @@ __device__ __forceinline__ void ks_word_carry(uint32_t s, uint32_t (&w)[4])
         M2("120", "120:121") M1("124:125", "y15") NOP0 AC("w3", "1", "UNUSED_PRESERVE")
         M2("122", "122:123") NOP1 AC("w3", "2", "UNUSED_PRESERVE")
         M2("124", "124:125") NOP1 AC("w3", "3", "UNUSED_PRESERVE")
+        NOP0 // (the compiler's hazard recognizer does not look inside the block: the wait state a consumer of w3 needs, below)
         : [w0] "+&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3)
         : [s] "v"(s), [bias] "v"(bias), [zero] "v"(zero), [m] "s"(m),
           [y1] "s"(2u * lcg::kBytePow.v[1]), [y2] "s"(2u * lcg::kBytePow.v[2]), [y3] "s"(2u * lcg::kBytePow.v[3]), [y4] "s"(2u * lcg::kBytePow.v[4]),
@@ -147,29 +154,23 @@ __device__ __forceinline__ void ks_word_carry(uint32_t s, uint32_t (&w)[4])
 #pragma clang diagnostic pop
 
 // Low bytes of the canonical states of bytes J0..J0+3 of the word whose first byte has
-// canonical state s, packed little-endian.
-template <int J0, int ALG> __device__ __forceinline__ uint32_t ks_state_dword(uint32_t s)
+// canonical state s, packed little-endian (ALG 1).
+template <int J0> __device__ __forceinline__ uint32_t ks_state_dword(uint32_t s)
 {
-    if constexpr (ALG == 0) {
-        auto lowbyte = [](uint32_t X) { return (X + (X >> 31)) & 0xFFu; };
-        uint32_t b0 = (J0 == 0) ? (s & 0xFFu) : lowbyte(state_x<(J0 == 0 ? 1 : J0)>(s));
-        return b0 | (lowbyte(state_x<J0 + 1>(s)) << 8) | (lowbyte(state_x<J0 + 2>(s)) << 16) |
-               (lowbyte(state_x<J0 + 3>(s)) << 24);
-    } else {
-        uint32_t w;
-        if constexpr (J0 == 0) w = s; // byte 0 of the word is the lane state itself; bytes 1..3 get overwritten
-        else put_byte<0>(w, state_x<(J0 == 0 ? 1 : J0)>(s));
-        put_byte<1>(w, state_x<J0 + 1>(s));
-        put_byte<2>(w, state_x<J0 + 2>(s));
-        put_byte<3>(w, state_x<J0 + 3>(s));
-        return w;
-    }
+    uint32_t w;
+    if constexpr (J0 == 0) w = s; // byte 0 of the word is the lane state itself; bytes 1..3 get overwritten
+    else put_byte<0>(w, state_x<(J0 == 0 ? 1 : J0)>(s));
+    put_byte<1>(w, state_x<J0 + 1>(s));
+    put_byte<2>(w, state_x<J0 + 2>(s));
+    put_byte<3>(w, state_x<J0 + 3>(s));
+    return w;
 }
 
 // data ^ keystream for one 16-byte word whose first byte has state s.
 // keystream = ~state_bytes  =>  data ^ ks = ~(data ^ state_bytes)  (one v_xnor per dword).
 template <int ALG> __device__ __forceinline__ u32x4 cycle_word(u32x4 d, uint32_t s)
 {
+    static_assert(ALG == 1 || ALG == 2, "the two keystream sequences the product ships");
     if constexpr (ALG == 2) {
         uint32_t w[4];
         ks_word_carry(s, w);
@@ -179,10 +180,10 @@ template <int ALG> __device__ __forceinline__ u32x4 cycle_word(u32x4 d, uint32_t
         d.w = ~(d.w ^ w[3]);
         return d;
     }
-    d.x = ~(d.x ^ ks_state_dword<0, ALG>(s));
-    d.y = ~(d.y ^ ks_state_dword<4, ALG>(s));
-    d.z = ~(d.z ^ ks_state_dword<8, ALG>(s));
-    d.w = ~(d.w ^ ks_state_dword<12, ALG>(s));
+    d.x = ~(d.x ^ ks_state_dword<0>(s));
+    d.y = ~(d.y ^ ks_state_dword<4>(s));
+    d.z = ~(d.z ^ ks_state_dword<8>(s));
+    d.w = ~(d.w ^ ks_state_dword<12>(s));
     return d;
 }
 
@@ -215,33 +216,26 @@ template <uint32_t CHUNK> __constant__ lcg::Table<256> c_chunk_pow0 = lcg::make_
 template <uint32_t CHUNK> __constant__ lcg::Table<256> c_chunk_pow1 = lcg::make_pow_table<256>((uint64_t)CHUNK << 8);
 template <uint32_t CHUNK> __constant__ lcg::Table<256> c_chunk_pow2 = lcg::make_pow_table<256>((uint64_t)CHUNK << 16);
 
-enum : int { MODE_FULL = 0, MODE_COPY = 1, MODE_COMPUTE = 2 };
 constexpr int AUX_NT = 2;   // buffer cache-policy bit: non-temporal (streaming) -- best for the loads (7.0 vs 6.4 TB/s read-only)
 constexpr int AUX_SC1 = 16; // system-coherent / write-through -- best for the stores (6.3 vs 5.9 TB/s write-only)
 
 } // namespace
-
-// U     = lane-words per thread per trip (independent 16-byte loads in flight per lane)
-// BLOCK = threads per workgroup; one workgroup trip covers U*BLOCK*16 contiguous bytes
-// ALG   = keystream instruction sequence (see ks_state_dword)
-// PIPE  = 0: load, compute, store per trip.  1: software pipeline, the next trip's loads are issued
-//         before this trip's arithmetic.  2: same, with a scheduling barrier that keeps the compiler
-//         from hoisting arithmetic above those loads.  3: as 2, and each word is stored as soon as it
-//         is finished instead of all U at the end of the trip
-// SYNC  = bit 0: workgroup barrier before each trip's loads, bit 1: before its stores -- keeps the
-//         16 waves of a workgroup in step so its 64 KiB of reads and of writes reach HBM as bursts
-// MODE  = MODE_FULL in the product; the other two are timing ablations for tools/tune_cycle
+// ---- the one-shot and the static streaming shape ------------------------------------------------------------------
+// U      = lane-words per thread per trip (independent 16-byte loads in flight per lane)
+// BLOCK  = threads per workgroup; one workgroup trip covers U*BLOCK*16 contiguous bytes
+// ALG    = keystream instruction sequence (see cycle_word)
+// STREAM = false: load, compute, store per trip -- the small shape (one word per thread, headers ... 256 MiB).
+//          true : software pipeline -- the next trip's loads are issued before this trip's arithmetic, behind a scheduling
+//                 barrier that keeps the compiler from hoisting arithmetic above them -- with a workgroup barrier in front
+//                 of each trip's loads and another in front of its stores, which keep the 16 waves of a workgroup in step
+//                 so its 128 KiB of reads and of writes reach HBM as bursts.
 //
 // Addressing is buffer_load/store_dwordx4 through a per-trip descriptor built from scalars:
 // no per-lane 64-bit pointer arithmetic in the loop, and the hardware range check (num_records =
 // bytes left in the body, capped at the chunk) drops the lanes past the end of a ragged last
-// chunk -- there is no tail branch.  Loads are `nt`, stores `sc1` (SAUX): measured best per direction
+// chunk -- there is no tail branch.  Loads are `nt`, stores `sc1`: measured best per direction
 // (profiles/r01_ubench_copy_policies.txt).
-// TRACE = 1 (tools/tune_cycle only): lane 0 of every workgroup records when it started and when each trip's
-//         stores had been issued (CycleArgs::trace)
-// LDSW  = 1 (tools/tune_cycle only; the north_star's "LDS as a write-combine stage", measured, not shipped):
-//         each trip's finished words go registers -> LDS -> registers before the store burst
-template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = AUX_SC1, int SYNC = 0, int TRACE = 0, int LDSW = 0>
+template <int U, int BLOCK, int ALG, bool STREAM>
 __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void modgpu_cycle_kernel(CycleArgs a)
 {
     static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
@@ -249,16 +243,6 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
     constexpr uint32_t SUB = BLOCK * lcg::WORD;                 // bytes per sub-step (one load per lane)
     const uint32_t tid = threadIdx.x;
     const uint32_t blk = blockIdx.x;
-    [[maybe_unused]] uint32_t trip = 0;
-    [[maybe_unused]] auto stamp = [&](uint32_t slot) {
-        if constexpr (TRACE != 0) {
-            if (tid == 0 && slot < 31) a.trace[blk * 32 + slot] = wall_clock64();
-        }
-    };
-    if constexpr (TRACE != 0) {
-        if (tid == 0) a.trace[blk * 32 + 31] = __builtin_amdgcn_s_getreg((20 | (0 << 6) | (3 << 11))); // HW_REG_XCC_ID[3:0]
-        stamp(0);
-    }
 
     // ---- ragged edges: < 16 bytes before / after the aligned body, done bytewise by block 0
     if (blk == 0 && tid < 32) cycle_edges(a, tid);
@@ -300,9 +284,8 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
         for (uint32_t u = 0; u < (uint32_t)U; ++u) {
             const uint32_t o = voff + u * SUB - (uint32_t)lead;
             u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, AUX_NT);
-            if constexpr (MODE == MODE_COPY) d = ~d;
-            else d = cycle_word<ALG>(d, su);
-            if constexpr (MODE != MODE_COMPUTE) __builtin_amdgcn_raw_buffer_store_b128(d, r, o, 0, SAUX);
+            d = cycle_word<ALG>(d, su);
+            __builtin_amdgcn_raw_buffer_store_b128(d, r, o, 0, AUX_SC1);
             su = mulmod_canon(su, lcg::kTileLo.v[BLOCK / 256]);
         }
 #pragma unroll
@@ -324,57 +307,24 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
     auto load = [&](u32x4(&d)[U], uint64_t o) {
         auto r = rsrc_at(o);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if constexpr (MODE == MODE_COMPUTE) d[u] = u32x4{tid, blk, (uint32_t)o, (uint32_t)u};
-            else d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, AUX_NT);
-        }
+        for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, AUX_NT);
     };
     auto process_store = [&](u32x4(&d)[U], uint64_t o) {
         auto r = rsrc_at(o);
-        if constexpr (PIPE == 3 && MODE == MODE_FULL) { // store each word as soon as it is done
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                d[u] = cycle_word<ALG>(d[u], s[u]);
-                __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
-                s[u] = mulmod_canon2(s[u], stride2);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            return;
-        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if constexpr (MODE == MODE_COPY) d[u] = ~d[u];
-            else {
-                d[u] = cycle_word<ALG>(d[u], s[u]);
-                s[u] = mulmod_canon2(s[u], stride2);
-            }
+            d[u] = cycle_word<ALG>(d[u], s[u]);
+            s[u] = mulmod_canon2(s[u], stride2);
         }
-        if constexpr (LDSW != 0) {
-            // write-combine stage: sub-step u's 16 KiB (BLOCK x 16 B) sits contiguously in LDS exactly as it
-            // will sit in HBM, then every lane reads its own word back.  Nothing is re-ordered -- the
-            // register layout is already the store layout -- so this measures the stage's price.
-            __shared__ u32x4 stage[U * BLOCK];
-#pragma unroll
-            for (int u = 0; u < U; ++u) stage[u * BLOCK + tid] = d[u];
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < U; ++u) d[u] = stage[u * BLOCK + tid];
-        }
-        if constexpr ((SYNC & 2) != 0 && PIPE != 0) {
+        if constexpr (STREAM) {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if constexpr (MODE == MODE_COMPUTE) {
-                if ((d[u].x ^ d[u].y ^ d[u].z ^ d[u].w) == 0x9E3779B9u && s[u] == 1u)
-                    __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
-            } else __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
-        }
-        stamp(++trip);
+        for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, AUX_SC1);
     };
 
-    if constexpr (PIPE == 0) {
+    if constexpr (!STREAM) {
         for (; off < end; off += step) {
             u32x4 d[U];
             load(d, off);
@@ -386,15 +336,15 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
         u32x4 d0[U], d1[U];
         load(d0, off);
         while (true) {
-            if constexpr (SYNC & 1) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
             load(d1, off + step);
-            if constexpr (PIPE >= 2) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
             process_store(d0, off);
             off += step;
             if (off >= end) break;
-            if constexpr (SYNC & 1) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
             load(d0, off + step);
-            if constexpr (PIPE >= 2) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
             process_store(d1, off);
             off += step;
             if (off >= end) break;
@@ -403,8 +353,8 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
 }
 
 // ---- the streaming kernel with a work queue ---------------------------------------------------------
-// Same lane layout, bursts, cache policies and arithmetic as modgpu_cycle_kernel<U, BLOCK, ALG, 2, MODE_FULL,
-// SAUX, 3> above; what differs is WHICH chunk a workgroup takes next.  With the static map (b, b+G, b+2G ...)
+// Same lane layout, bursts and arithmetic as the static streaming shape above (modgpu_cycle_kernel<U, BLOCK, 2, true>);
+// what differs is WHICH chunk a workgroup takes next.  With the static map (b, b+G, b+2G ...)
 // every workgroup does the same number of trips, but the CUs are not equally fast: the workgroups of every
 // other XCD take ~9.6 us per trip, the rest ~11 us (profiles/r02_trace_static_schedule.txt), so half the
 // chip idles at the end of every launch while the other half finishes.  Here a workgroup's first three
@@ -426,19 +376,16 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
 // after that barrier.  a.queue[0] is the ticket counter, a.queue[1] counts workgroups that are done; the last one out
 // zeroes both, so the pair is clean for the next launch without a memset, and then writes a.queue_seq to the host-visible
 // word a.queue_done: the host hands a pair to a new launch only after its previous user has signed off there.
-// DEPTH = chunks of loads a workgroup keeps in flight ahead of the one it computes (1 = ping-pong as above)
-// MODE  = MODE_FULL in the product; MODE_COPY (tools/tune_cycle) is the same loop without the keystream: the
-//         memory system's ceiling for this access pattern
-// LAUX  = cache-policy bits of the loads (AUX_NT in the product); B1 = 0 drops the barrier in front of each trip's
-//         load burst (tools/tune_cycle only)
-// B2    = 0 (tools/tune_cycle, TIMING ONLY -- results are wrong): drops the second barrier too, so the ticket
-//         hand-off races; answers what a barrier-free workgroup would gain.  B2 = 2 (tools/tune_cycle): the
-//         barrier sits behind the store burst instead of in front of it (waves store as they finish)
-template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int LAUX = AUX_NT, int B1 = 1, int B2 = 1>
+// One chunk of loads is in flight ahead of the one being computed (ping-pong); nt loads, sc1+nt stores; a workgroup barrier
+// in front of each trip's load burst and another in front of its store burst (the second is also what orders the ticket
+// hand-off).  Deeper pipelines, other barrier placements and cache policies were measured in tools/ and lost.
+template <int U, int BLOCK>
 __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void modgpu_cycle_queue_kernel(CycleQueueArgs a)
 {
     static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
-    static_assert(DEPTH >= 1 && DEPTH <= 3, "1..3 chunks of loads in flight");
+    constexpr int ALG = 2;                   // the three-instruction keystream (ks_word_carry)
+    constexpr int SAUX = AUX_SC1 | AUX_NT;   // stores: write-through, streaming
+    constexpr int DEPTH = 1;                 // chunks of loads in flight ahead of the one being computed
     constexpr uint32_t CHUNK = (uint32_t)U * BLOCK * lcg::WORD;
     constexpr uint32_t SUB = BLOCK * lcg::WORD;
     constexpr int NB = DEPTH + 1;     // register buffers: one being computed, DEPTH being loaded
@@ -456,15 +403,6 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
     // read can be overtaken by lane 0's next write -- tools/tune_cycle's INVALID row shows what that looks like.)
     __shared__ uint32_t q_next[2];
     uint32_t trip = 0;
-    [[maybe_unused]] auto stamp = [&](uint32_t slot) {
-        if constexpr (TRACE != 0) {
-            if (tid == 0 && slot < 31) a.trace[blk * 32 + slot] = wall_clock64();
-        }
-    };
-    if constexpr (TRACE != 0) {
-        if (tid == 0) a.trace[blk * 32 + 31] = __builtin_amdgcn_s_getreg((20 | (0 << 6) | (3 << 11)));
-        stamp(0);
-    }
     const uint32_t voff = tid * lcg::WORD;
     // a^(4096*(tid/256)) * a^(16*(tid%256)): this lane's word 0 relative to the start of any chunk
     const uint32_t lane_mul = mulmod_canon(c_tile_lo.v[tid >> 8], c_lane_pow.v[tid & 255]);
@@ -533,7 +471,7 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
         locate(g, vl);
         auto r = rsrc_at(g, vl);
 #pragma unroll
-        for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, LAUX);
+        for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, AUX_NT);
     };
     // Lane 0's ticket traffic.  The returning atomic is a plain compiler-visible atomic, so the compiler counts it
     // in its own s_waitcnt vmcnt(N) bookkeeping and waits for the value only where it is published, a trip
@@ -549,28 +487,18 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
     auto process_store = [&](u32x4(&d)[U], uint32_t g, bool publish) {
         locate(g, vs);
         auto r = rsrc_at(g, vs);
-        if constexpr (MODE == MODE_COPY) {
+        uint32_t s[U];
+        states(g, vs, s);
 #pragma unroll
-            for (int u = 0; u < U; ++u) d[u] = ~d[u];
-        } else {
-            uint32_t s[U];
-            states(g, vs, s);
-#pragma unroll
-            for (int u = 0; u < U; ++u) d[u] = cycle_word<ALG>(d[u], s[u]);
-        }
+        for (int u = 0; u < U; ++u) d[u] = cycle_word<ALG>(d[u], s[u]);
         if (publish && tid == 0) // (the LDS write has landed before the barrier releases the readers)
             asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(q_next_lds + 4u * (trip & 1u)), "v"(pending) : "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (B2 == 1) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         if (tid == 0) pending = __hip_atomic_fetch_add(a.queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
-        if constexpr (B2 == 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-        }
         ++trip;
-        stamp(trip);
     };
     auto take_published = [&]() { // every lane, after the trip's barrier (trip already counted: the word is (trip-1)&1)
         uint32_t t;
@@ -628,7 +556,7 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
         while (!finished) {
 #pragma unroll
             for (int p = 0; p < NB; ++p) {
-                if constexpr (B1 != 0) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
                 load(d[(p + DEPTH) % NB], cq[DEPTH]);
                 __builtin_amdgcn_sched_barrier(0);
                 process_store(d[p], cq[0], publish);

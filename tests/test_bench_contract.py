@@ -37,11 +37,11 @@ def test_traffic_is_replayed_only_for_the_same_device_code(modgpu, tmp_path):
             "import modulate_amd as M\n"
             "s = json.load(open(bench.ROOT + '/profiles/pmc_summary.json'))\n"
             "h = M.kernel_source_hash()\n"
-            "k = 'modgpu_cycle_kernel<8, 1024, 1, 2, 0, 16, 3>'\n"
+            "k = 'modgpu_cycle_kernel<8, 1024, 2, true>'\n"
             "r = {'same': bench.load_traffic(int(s['part_bytes']), s['cycle_kernel'].split('(')[0].replace('void ', ''), s.get('kernel_source_hash')),\n"
             "     'other_hash': bench.load_traffic(int(s['part_bytes']), k, '0' * 64),\n"
             "     'other_size': bench.load_traffic(12345, k, s.get('kernel_source_hash')),\n"
-            "     'other_kernel': bench.load_traffic(int(s['part_bytes']), 'modgpu_cycle_kernel<1, 256, 1, 0, 0, 16, 0>', s.get('kernel_source_hash')),\n"
+            "     'other_kernel': bench.load_traffic(int(s['part_bytes']), 'modgpu_cycle_kernel<1, 256, 1, false>', s.get('kernel_source_hash')),\n"
             "     'loaded_matches': s.get('kernel_source_hash') == h}\n"
             "print('RESULT', json.dumps(r))\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT))

@@ -351,7 +351,7 @@ def test_bench_two_ranks_rehearsal(host, tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3 and out["unit"] == "GB/s"
     assert "config 3" in out["config"]["workload"] and out["config"]["bit_exact_check"].startswith("pass")
-    assert out["roofline"]["kernel"].startswith("modgpu_cycle_queue_kernel<4, 1024,") and out["roofline"]["main_workgroups"] == 200 and out["roofline"]["grid"] == 256
+    assert out["roofline"]["kernel"].startswith("modgpu_cycle_queue_kernel<4, 1024>") and out["roofline"]["main_workgroups"] == 200 and out["roofline"]["grid"] == 256
     assert "cpu_baseline" not in out  # rank 0 at N=1 only
     assert abs(out["value"] - 2 * 3 * 2 * (320 << 20) / (out["ms_per_step"] * 3 * 1e-3) / 1e9) / out["value"] < 0.01
 
@@ -373,7 +373,7 @@ def test_bench_nccl_branch_single_rank(host):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["config"]["bit_exact_check"].startswith("pass")
-    assert out["roofline"]["kernel"].startswith("modgpu_cycle_queue_kernel<4, 1024,")
+    assert out["roofline"]["kernel"].startswith("modgpu_cycle_queue_kernel<4, 1024>")
     # the first-pass figures beside the steady state, and which launches the events bracket
     fp = out["roofline"]["first_pass"]
     assert fp["part"]["bytes"] == 320 << 20 and fp["part"]["ms"] > 0 and len(fp["ms_of_launches_1_to_12"]) == 12

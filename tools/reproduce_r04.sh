@@ -1,0 +1,23 @@
+#!/bin/bash
+# tools/reproduce_r04.sh -- every command behind the round-4 tables in profiles/, grouped in blocks sized for one gpurun call.
+# Run from the repo root on the GPU box.  Outputs go to gpurun_out/; the summaries that are kept were copied into profiles/.
+set -e
+O=gpurun_out
+mkdir -p $O
+case "${1:-help}" in
+build)        # on the build box (cross-compiles without a GPU); the binaries travel with the snapshot
+    make -s -C modulate_amd/csrc all && make -s -C tools tune_cycle ubench_queue_rw first_pass ;;
+tail)         # profiles/r04_tail.txt: where a sub-GiB launch's time goes, and the tail variants
+    timeout -k 10 120 tools/tune_cycle selftest > $O/r04_selftest.txt
+    for v in 0 1 2 3 4; do
+      timeout -k 10 120 tools/tune_cycle trace 411000000 200 1 $v 400 0 $((v==0)) > $O/r04_trace_411MB_v$v.txt
+      timeout -k 10 120 tools/tune_cycle trace 104857600 200 1 $v 400 1 $((v==0)) > $O/r04_trace_100MB_cold_v$v.txt
+    done
+    timeout -k 10 120 tools/tune_cycle trace 411000000 200 1 0 0 1 0 > $O/r04_trace_411MB_cold_v0.txt
+    timeout -k 10 400 tools/tune_cycle 411000000 7 > $O/r04_tune_411MB.txt
+    timeout -k 10 400 tools/tune_cycle 104857600 7 1 > $O/r04_tune_100MB_cold.txt
+    timeout -k 10 400 tools/tune_cycle 4294967296 3 > $O/r04_tune_4GiB.txt ;;
+memside)      # profiles/r04_memside_counters.json
+    bash tools/memside_counters.sh 4294967296 ;;
+*) echo "usage: tools/reproduce_r04.sh build | tail | memside" ;;
+esac

@@ -22,7 +22,7 @@ static void launch_cycle(uint8_t *p, uint64_t n, hipStream_t st, uint32_t grid)
     a.head_ptr = p; a.head_n = 0; a.body = p; a.body_words = n / 16; a.tail_ptr = p + n; a.tail_n = 0; a.lead = 0;
     a.base_head = a.base_body = a.base_tail = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
     a.stride_mul2 = 2u * lcg::powmod(lcg::A, ((uint64_t)grid * 131072) % lcg::PERIOD);
-    hipLaunchKernelGGL((modgpu_cycle_kernel<8, 1024, 1, 2, MODE_FULL, 16, 3>), dim3(grid), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL((modgpu_cycle_kernel<8, 1024, 2, true>), dim3(grid), dim3(1024), 0, st, a);
 }
 
 static void par_memcpy(void *d, const void *s, size_t n, int threads)

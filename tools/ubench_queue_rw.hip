@@ -2,17 +2,20 @@
 // writes, or copies in place: the ceilings the cycle kernel (read + compute + write in place) sits under.
 // Same schedule as modgpu_cycle_queue_kernel (64 KiB chunks, 1024-thread workgroups, static prefix of 3 + tickets
 // fetched a trip ahead, nt loads, sc1 nt stores, both workgroup barriers), no arithmetic.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-atomic-optimizer-strategy=None tools/ubench_queue_rw.hip -o tools/ubench_queue_rw
-// Run:   tools/ubench_queue_rw [bytes=4294967296] [grid=200]
+// Round 4: the fourth row is the PRODUCT kernel itself (modgpu_cycle_queue_kernel<4, 1024> from the product header), so that one
+// `rocprofv3 --pmc` pass over this program reads the memory-side counters of all four under the same conditions
+// (tools/memside_counters.sh, profiles/r04_memside_counters.json).
+// Build: make -C tools ubench_queue_rw
+// Run:   tools/ubench_queue_rw [bytes=4294967296] [grid=200] [rounds=8]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include "cycle_kernel_impl.h"
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
-using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
-enum { READ = 0, WRITE = 1, COPY = 2 };
+enum { READ = 0, WRITE = 1, COPY = 2, FULL = 3 };
 constexpr int U = 4, BLOCK = 1024;
 constexpr uint32_t SUB = BLOCK * 16, CHUNK = U * SUB;
 
@@ -99,39 +102,49 @@ int main(int argc, char **argv)
 {
     uint64_t n = argc > 1 ? strtoull(argv[1], nullptr, 0) : (1ull << 32);
     uint32_t grid = argc > 2 ? (uint32_t)atoi(argv[2]) : 200u;
+    const int rounds = argc > 3 ? atoi(argv[3]) : 8;
     uint8_t *buf;
     uint32_t *queue, *sink;
     CHECK(hipMalloc(&buf, n));
     CHECK(hipMemset(buf, 0x5A, n));
-    CHECK(hipMalloc(&queue, 64));
-    CHECK(hipMemset(queue, 0, 64));
+    CHECK(hipMalloc(&queue, 256));
+    CHECK(hipMemset(queue, 0, 256));
     CHECK(hipMalloc(&sink, 4096 * 4));
     hipStream_t st;
     CHECK(hipStreamCreate(&st));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    const char *names[3] = {"read-only ", "write-only", "copy r+w  "};
-    std::vector<float> ms[3];
-    for (int r = 0; r < 8; ++r)
-        for (int m = 0; m < 3; ++m) {
+    const char *names[4] = {"read-only ", "write-only", "copy r+w  ", "PRODUCT   "};
+    std::vector<float> ms[4];
+    // the product kernel's table of one part (the buffer is chunk-aligned: no lead, no edges)
+    CycleQueueArgs qa{};
+    qa.queue = queue + 32; // a line of its own
+    qa.n_parts = 1;
+    qa.part[0].body = buf;
+    qa.part[0].end = n / 16 * 16;
+    qa.part[0].base_body = qa.part[0].base_head = qa.part[0].base_tail = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
+    for (int k = 1; k <= kCycleBatchMax; ++k) qa.start[k] = (uint32_t)((qa.part[0].end + CHUNK - 1) / CHUNK);
+    for (int r = 0; r < rounds; ++r)
+        for (int m = 0; m < 4; ++m) {
             CHECK(hipEventRecord(e0, st));
             for (int k = 0; k < 2; ++k) {
                 if (m == READ) hipLaunchKernelGGL(rw_kernel<READ>, dim3(grid), dim3(BLOCK), 0, st, buf, n, queue, sink);
                 else if (m == WRITE) hipLaunchKernelGGL(rw_kernel<WRITE>, dim3(grid), dim3(BLOCK), 0, st, buf, n, queue, sink);
-                else hipLaunchKernelGGL(rw_kernel<COPY>, dim3(grid), dim3(BLOCK), 0, st, buf, n, queue, sink);
+                else if (m == COPY) hipLaunchKernelGGL(rw_kernel<COPY>, dim3(grid), dim3(BLOCK), 0, st, buf, n, queue, sink);
+                else hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, qa);
             }
             CHECK(hipEventRecord(e1, st));
             CHECK(hipEventSynchronize(e1));
             float t;
             CHECK(hipEventElapsedTime(&t, e0, e1));
-            if (r >= 2) ms[m].push_back(t / 2);
+            if (r >= 2 || rounds < 3) ms[m].push_back(t / 2);
         }
     CHECK(hipGetLastError());
     printf("bytes=%llu grid=%u, work-queue schedule, 64 KiB chunks (GB/s of HBM traffic: n for read-only / write-only, 2n for copy)\n", (unsigned long long)n, grid);
-    for (int m = 0; m < 3; ++m) {
+    for (int m = 0; m < 4; ++m) {
         std::sort(ms[m].begin(), ms[m].end());
-        const double traffic = (m == COPY ? 2.0 : 1.0) * n;
+        const double traffic = (m >= COPY ? 2.0 : 1.0) * n;
         printf("  %s  median %.4f ms -> %7.1f GB/s   best %7.1f\n", names[m], ms[m][ms[m].size() / 2], traffic / ms[m][ms[m].size() / 2] / 1e6,
                traffic / ms[m].front() / 1e6);
     }
