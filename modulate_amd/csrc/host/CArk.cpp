@@ -281,13 +281,26 @@ eError CArk::ParseHeader( std::vector< unsigned char > lImage )
 // ------------------------------------------------------------------------------------ parts in
 // Runs lWork( part index, device ) for every part, part i on GPU i mod N, one host thread per GPU
 // (no inter-GPU traffic: parts are independent streams).  Returns the first failure.
+// On a host WITHOUT a GPU the part cipher is still defined -- it is Cycle over a part, and the reference's Cycle cannot
+// fail (CEncryptionCycler.cpp:4-14) -- so the parts go, one after another, through the library's own host loop
+// (lWork( i, -1 ): device -1 = no device; modgpu_cycle_auto_host, which threads large buffers itself).  This is "the build's
+// CPU path" BASELINE config 5 byte-diffs the GPU output against.  MODGPU_REQUIRE_GPU=1 forbids it, as everywhere.
 template < typename F > static eError ForEachPartOnDevices( size_t liNumParts, int liNumDevices, F lWork )
 {
     int liAvailable = modgpu_device_count();
     if( liAvailable <= 0 )
     {
-        std::printf( "ERROR: GPU part cipher failed: no HIP device visible\n" );
-        return eError_InvalidData;
+        if( modgpu_gpu_required() )
+        {
+            std::printf( "ERROR: GPU part cipher failed: no HIP device visible\n" );
+            return eError_InvalidData;
+        }
+        for( size_t i = 0; i < liNumParts; ++i )
+        {
+            eError leError = lWork( i, -1 );
+            if( leError != eError_NoError ) return leError;
+        }
+        return eError_NoError;
     }
     if( liNumDevices <= 0 || liNumDevices > liAvailable ) liNumDevices = liAvailable;
     liNumDevices = (int)std::min< size_t >( (size_t)liNumDevices, std::max< size_t >( liNumParts, 1 ) );
@@ -336,6 +349,16 @@ eError CArk::LoadArkData() // CArk.cpp:723-758
     // the buffer (pread / H2D / kernel / D2H overlapped, modgpu_cycle_file_to_host), part i on GPU i mod N.
     const int liKey = miLoadedKey ? miLoadedKey : (int)CSettings::Current().muKey;
     eError leError = ForEachPartOnDevices( maArks.size(), miPartDevices, [ & ]( size_t ii, int liDevice ) {
+        if( liDevice < 0 ) // no GPU on this host: read the part as the reference does (CArk.cpp:751), then Cycle's host engine
+        {
+            uint8_t* lpSlice = reinterpret_cast< uint8_t* >( maArkData.data() ) + lOffsets[ ii ];
+            FILE* f = std::fopen( lPaths[ ii ].c_str(), "rb" );
+            if( !f ) return eError_FailedToOpenFile;
+            size_t got = maArks[ ii ].muSize ? std::fread( lpSlice, 1, maArks[ ii ].muSize, f ) : 0;
+            std::fclose( f );
+            if( got != maArks[ ii ].muSize ) return eError_InvalidData;
+            return modgpu_cycle_auto_host( lpSlice, maArks[ ii ].muSize, liKey, 0, -1 ) == MODGPU_OK ? eError_NoError : eError_InvalidData;
+        }
         int liStatus = modgpu_cycle_file_to_host( lPaths[ ii ].c_str(), 0, reinterpret_cast< uint8_t* >( maArkData.data() ) + lOffsets[ ii ],
                                                   maArks[ ii ].muSize, liKey, 0, liDevice );
         if( liStatus == MODGPU_OK ) return eError_NoError;
@@ -359,6 +382,12 @@ eError CArk::CycleArkData( int liKey, int liNumDevices ) // addition: north_star
         luOffset += a.muSize;
     }
     if( lParts.empty() ) return eError_NoError;
+    if( modgpu_device_count() <= 0 && !modgpu_gpu_required() ) // no GPU on this host: every part through Cycle's host engine
+    {
+        for( size_t i = 0; i < lParts.size(); ++i )
+            if( modgpu_cycle_auto_host( lParts[ i ], lSizes[ i ], liKey, 0, -1 ) != MODGPU_OK ) return eError_InvalidData;
+        return eError_NoError;
+    }
     int liStatus = modgpu_cycle_parts_host( lParts.data(), lSizes.data(), (int)lParts.size(), liKey, liNumDevices );
     if( liStatus != MODGPU_OK )
     {
@@ -770,6 +799,23 @@ eError CArk::SaveArk( const char* lpOutputDirectory, const char* lpHeaderFilenam
     const int liPartKey = (int)CSettings::Current().muKey; // on save the key follows the platform switch
     leError = ForEachPartOnDevices( lJobs.size(), miPartDevices, [ & ]( size_t ii, int liDevice ) {
         const sJob& j = lJobs[ ii ];
+        if( liDevice < 0 ) // no GPU on this host: the slice goes through Cycle's host engine in pieces of a scratch buffer
+        {                  // (the in-memory slice stays as it was), each piece at its own stream offset
+            FILE* f = std::fopen( j.mFilename.c_str(), "wb" );
+            if( !f ) return eError_FailedToCreateFile;
+            constexpr uint64_t kuPiece = 64ull << 20;
+            std::vector< uint8_t > lPiece( (size_t)std::min< uint64_t >( kuPiece, j.muSize ) );
+            eError leResult = eError_NoError;
+            for( uint64_t luAt = 0; luAt < j.muSize && leResult == eError_NoError; luAt += kuPiece )
+            {
+                const uint64_t luLen = std::min< uint64_t >( kuPiece, j.muSize - luAt );
+                std::memcpy( lPiece.data(), maArkData.data() + j.muSlice + luAt, luLen );
+                if( modgpu_cycle_auto_host( lPiece.data(), luLen, liPartKey, luAt, -1 ) != MODGPU_OK ) leResult = eError_InvalidData;
+                else if( std::fwrite( lPiece.data(), 1, luLen, f ) != luLen ) leResult = eError_FailedToWriteData;
+            }
+            std::fclose( f );
+            return leResult;
+        }
         int liStatus = modgpu_cycle_host_to_file( reinterpret_cast< const uint8_t* >( maArkData.data() ) + j.muSlice, j.muSize,
                                                   j.mFilename.c_str(), liPartKey, 0, liDevice );
         if( liStatus == MODGPU_OK ) return eError_NoError;

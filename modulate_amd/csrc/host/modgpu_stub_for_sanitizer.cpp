@@ -20,6 +20,11 @@ int modgpu_cycle_auto_host( uint8_t* buf, uint64_t n, int32_t key, uint64_t off,
 }
 int modgpu_cycle_parts_host( uint8_t* const*, const uint64_t*, int, int32_t, int ) { return MODGPU_ERR_NO_DEVICE; }
 int modgpu_device_count( void ) { return 0; }
+int modgpu_gpu_required( void )
+{
+    const char* e = std::getenv( "MODGPU_REQUIRE_GPU" );
+    return e && *e && *e != '0';
+}
 int modgpu_cycle_file_to_host( const char*, uint64_t, uint8_t*, uint64_t, int32_t, uint64_t, int ) { return MODGPU_ERR_NO_DEVICE; }
 int modgpu_cycle_host_to_file( const uint8_t*, uint64_t, const char*, int32_t, uint64_t, int ) { return MODGPU_ERR_NO_DEVICE; }
 int modgpu_host_alloc( void** p, uint64_t n ) { *p = std::malloc( n ? n : 1 ); return *p ? MODGPU_OK : MODGPU_ERR_INVALID; }

@@ -349,60 +349,27 @@ def test_device_alias_needs_a_device(modgpu):
     assert r.returncode == 0 and "COUNT 0" in r.stdout, r.stdout + r.stderr
 
 
-def test_queue_kernel_codegen_keeps_the_ticket_atomic_asynchronous():
-    """The work-queue kernel's ticket fetch must stay ONE plain returning atomic whose value is waited for a
-    trip later.  LLVM's atomic optimizer (on by default) rewrites it into a wave-aggregated atomic followed at
-    once by s_waitcnt vmcnt(0) -- correct, but the wave then sits out every load it has in flight, each trip.
-    The Makefile passes -amdgpu-atomic-optimizer-strategy=None for that TU; this test compiles the TU with the
-    Makefile's flags and looks at the gfx950 ISA."""
-    import shutil
+def test_kernel_codegen_guard_passes_the_tree_and_rejects_a_broken_build():
+    """The streaming kernels' keystream is a hand-scheduled assembly block in FIXED registers; the work-queue kernel's ticket
+    fetch must stay one plain returning atomic.  Whether the compiler kept to that is visible only in its output, so
+    modulate_amd/csrc/check_isa.py reads the gfx950 assembly -- `make` runs it before it will produce cycle_kernel.o.  Here:
+    the tree's TU passes, and a build with an input of the block pinned into one of its fixed temporaries (round 3's
+    wrong-keystream build) is REJECTED.  hipcc is part of the build container: its absence is a failure, not a skip."""
     hipcc = "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("hipcc not installed")
+    assert os.path.exists(hipcc), "hipcc is missing: the code-generation guard cannot run, and that is not acceptable for a build box"
     csrc = os.path.join(ROOT, "modulate_amd", "csrc")
     flags = subprocess.run(["make", "-s", "-C", csrc, "--eval", "print-kflags: ; @echo $(KERNEL_FLAGS)", "print-kflags"],
                            capture_output=True, text=True).stdout.split()
     assert "-amdgpu-atomic-optimizer-strategy=None" in flags, flags
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S", "--cuda-device-only",
-                        os.path.join(csrc, "cycle_kernel.hip"), "-o", "-"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    asm = r.stdout
-    start = asm.index("_Z25modgpu_cycle_queue_kernel")
-    body = asm[asm.index(":", start):asm.index("s_endpgm", start)]
-    assert "v_mbcnt" not in body, "the atomic optimizer rewrote the ticket atomic"
-    assert body.count("global_atomic_add") == 4  # one ticket fetch per unrolled trip (2) + a helper's first three tickets + the exit count
-    assert "scratch_" not in body and "flat_" not in body  # no spills, LDS mailbox accessed with ds_ instructions
-    assert body.count("ds_write_b32") == 3 and body.count("ds_read_b32") == 3  # ticket mailbox (2 + 2) and the helper workgroups' first ticket
-    loads = [ln for ln in body.splitlines() if "buffer_load_dwordx4" in ln]
-    stores = [ln for ln in body.splitlines() if "buffer_store_dwordx4" in ln]
-    assert loads and all(ln.rstrip().endswith(" nt") for ln in loads), loads[:2]
-    hot_stores = [ln for ln in stores if ln.rstrip().endswith("nt sc1")]
-    assert len(hot_stores) >= 8  # 4 words x 2 unrolled trips (+ the cold peel loop)
-    assert shutil.which("make")
-    # ---- the keystream sequence (ALG 2, ks_word_carry): per byte two v_mad_u64_u32 and ONE v_addc_co_u32_sdwa that takes the
-    # canonicalising +1 from the fold's carry-out -- no shift, no separate add
-    assert body.count("v_addc_co_u32_sdwa") == 9 * 15  # 4 words x 2 unrolled trips + the peeled first chunk, 15 bytes each
-    assert "v_add_u32_sdwa" not in body
-    # ... whose hand-scheduled block works in FIXED temporaries, v[120:127] and s[94:95], kept out of the register allocator's
-    # reach by amdgpu_num_vgpr(120) / amdgpu_num_sgpr(94) on the kernels.  Nothing outside the blocks may touch them, and no
-    # operand the compiler chose for a block may lie inside them (as plain clobbers it did hand them to inputs: wrong bytes).
-    fixed = re.compile(r"\bv12[0-7]\b|v\[\d+:12[0-7]\]|\bs9[45]\b|s\[\d+:9[45]\]")
-    # the part table (one or several buffers per launch) is read where it lies, in the kernel arguments: no scratch copy
-    meta = asm[asm.index(".name:", asm.index("amdhsa.kernels")):]
-    qmeta = meta[meta.index("_Z25modgpu_cycle_queue_kernel"):]
-    assert ".private_segment_fixed_size: 0" in qmeta[:qmeta.index(".wavefront_size")]
-    for name in ("_Z25modgpu_cycle_queue_kernel", "_Z19modgpu_cycle_kernelILi8ELi1024ELi2"):
-        st = asm.index(name)
-        fn = asm[asm.index(":", st):asm.index("s_endpgm", st)]
-        blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", fn, flags=re.S)
-        carry = [b for b in blocks if "s[94:95]" in b]
-        assert carry, name
-        outside = re.sub(r";;#ASMSTART\n.*?;;#ASMEND", "", fn, flags=re.S)
-        assert not [ln for ln in outside.splitlines() if fixed.search(ln) and not ln.strip().startswith(";")], name
-        for b in carry:
-            for ln in b.splitlines():
-                chosen = re.sub(r"v\[12[0246]:12[1357]\]|s\[94:95\]|\bv12[0246]\b|\bv127\b", "", ln)  # what is left was allocated by the compiler
-                assert not fixed.search(chosen), ln
+    good = subprocess.run(["make", "-s", "-C", csrc, "isa-check"], capture_output=True, text=True, timeout=900)
+    assert good.returncode == 0 and "check_isa: ok (3 kernels)" in good.stdout, good.stdout[-3000:] + good.stderr[-2000:]
+    broken = subprocess.run(["make", "-s", "-C", csrc, "isa-check-broken"], capture_output=True, text=True, timeout=900)
+    assert broken.returncode != 0, "the guard accepted a build whose keystream block reads a register the block overwrites"
+    assert "the compiler gave a block operand a fixed temporary" in broken.stdout, broken.stdout[-3000:]
+    # the object file rule depends on the guard: a TU that fails it produces no cycle_kernel.o
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    rule = mk[mk.index("cycle_kernel.o:"):mk.index("isa-check:")]
+    assert rule.index("check_isa.py cycle_kernel.s") < rule.index("-c cycle_kernel.hip")
 
 
 @pytest.mark.parametrize("env,want", [

@@ -146,6 +146,66 @@ def test_config1_cycle_cannot_fail_without_gpu(host, modgpu, oracle, tmp_path):
 
 
 @needs_host_loop
+def test_part_cipher_on_a_host_without_gpu(host, modgpu, oracle, header_cwd, tmp_path):
+    """BASELINE config 5 says "byte-diff vs the build's CPU path": the part cipher (north_star: Cycle over part-sized
+    buffers beside LoadArkData / lSaveArk, CArk.cpp:723-758, 845-899) is defined on a GPU-less host too -- the parts go
+    through the library's own host loop, as Cycle itself does there.  Encrypted parts == oracle Cycle of the raw slices,
+    `-cryptparts -unpack` restores every file, `-cryptparts -pack` writes parts that oracle-decrypt to the files at their
+    offsets, and MODGPU_REQUIRE_GPU=1 refuses instead of computing."""
+    if modgpu.device_count() > 0:
+        pytest.skip("GPU present")
+    host.select_platform(True)
+    rng = np.random.default_rng(55)
+    n = 300
+    names = [f"dir{k % 7}/sub{k % 3}/f{k}.bin" for k in range(n)]
+    sizes = [int(x) for x in rng.integers(0, 300_000, size=n)]
+    data = rng.integers(0, 256, size=sum(sizes), dtype=np.uint8)
+    offs = np.cumsum([0] + sizes)
+    first = str(tmp_path / "first") + "/"
+    os.makedirs(first)
+    a = host.Ark()
+    a.construct_from_table(names, sizes, 3, "main_ps4")
+    a.build_from_memory(data)
+    a.enable_part_cipher(True, 8)
+    a.save(first, "main_ps4.hdr")
+    assert np.array_equal(a.data(), data)  # SaveArk leaves the in-memory slices as they were
+    off = 0
+    for path, size in zip(a.ark_paths(), a.ark_sizes()):
+        assert np.array_equal(np.fromfile(first + path, dtype=np.uint8), oracle.cycle(data[off:off + size].copy(), oracle.KEY_PS4)), path
+        off += size
+    b = host.Ark().load(first + "main_ps4.hdr")
+    b.enable_part_cipher(True, 8)
+    b.load_data()
+    assert np.array_equal(b.data(), data)
+    b.cycle_parts(oracle.KEY_PS4, 8)  # the in-memory form (CycleArkData): every part its own stream from offset 0
+    off = 0
+    for size in b.ark_sizes():
+        assert np.array_equal(b.data()[off:off + size], oracle.cycle(data[off:off + size].copy(), oracle.KEY_PS4))
+        off += size
+    a.close(), b.close()
+    unpacked, packed = str(tmp_path / "u"), str(tmp_path / "p")
+    os.makedirs(packed)
+    env = {k: v for k, v in os.environ.items() if k != "MODGPU_REQUIRE_GPU"}
+    r = subprocess.run([EXE, "-cryptparts", "-gpus", "8", "-unpack", first, unpacked], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "Complete!" in r.stdout, r.stdout[-2000:] + r.stderr
+    for nm, s_, o in zip(names, sizes, offs):
+        assert np.array_equal(np.fromfile(os.path.join(unpacked, nm), dtype=np.uint8), data[o:o + s_]), nm
+    r = subprocess.run([EXE, "-cryptparts", "-gpus", "8", "-pack", first, unpacked, packed], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "Complete!" in r.stdout, r.stdout[-2000:] + r.stderr
+    c = host.Ark().load(packed + "/main_ps4.hdr")
+    raw = np.concatenate([oracle.cycle(np.fromfile(os.path.join(packed, p), dtype=np.uint8), oracle.KEY_PS4) for p in c.ark_paths()])
+    by_name = dict(zip(names, zip(offs, sizes)))
+    assert sorted(f["name"] for f in c.files()) == sorted(names)
+    for f in c.files():
+        o, s_ = by_name[f["name"]]
+        assert f["size"] == s_ and np.array_equal(raw[f["offset"]:f["offset"] + s_], data[o:o + s_]), f["name"]
+    c.close()
+    strict = subprocess.run([EXE, "-cryptparts", "-unpack", first, str(tmp_path / "never")], capture_output=True, text=True,
+                            env=dict(env, MODGPU_REQUIRE_GPU="1"))
+    assert strict.returncode != 0 and "no HIP device visible" in strict.stdout, strict.stdout[-1000:]
+
+
+@needs_host_loop
 def test_header_save_load_framing_without_gpu(host, modgpu, oracle, header_cwd, tmp_path):
     """SaveArk / Load framing (CArk.cpp:914-915, 1135-1136, 328-339) on a GPU-less host: header on disk ==
     oracle ciphertext of the plain image; Load decrypts it back; parts are raw slices."""
