@@ -47,6 +47,35 @@ int modgpu_last_launch(modgpu_launch_info_t *out);
  * (MODGPU_HOST_PIPES), out[1] = largest slot in bytes (MODGPU_HOST_CHUNK_MB), out[2] = largest buffer cycled in
  * one pinned slot without chunking (MODGPU_HOST_ZEROCOPY_KB, never above out[1]), out[3] = DMA ring depth. */
 void modgpu_host_tunables(uint64_t out[4]);
+/* ... and the two that shape the chunks of a staged buffer: out[0] = MODGPU_HOST_SPLIT (a buffer is cut into about this many
+ * chunks), out[1] = smallest such chunk in bytes (MODGPU_HOST_CHUNK_MIN_MB, never above the largest slot). */
+void modgpu_host_chunking(uint64_t out[2]);
+
+/* Host-side timeline of the host-buffer / file routes: while enabled, every call of modgpu_cycle_host and
+ * the file entry points records what it did and when (CLOCK_MONOTONIC ns): the call's begin and end, the slots it got
+ * (chunk = pipelines, bytes = slot size), its pipelines posted to the device's parked workers, and per pipeline and chunk:
+ * fill begin / end (memcpy or pread into the slot), the kernel launch returning, the wait for the kernel (sync begin / end),
+ * the drain's end (memcpy or pwrite out of the slot).  pipe = -1 for call-level events.  Recording costs a clock read and a
+ * short lock per event; disabled (the default) it is one relaxed load.  bin/modbench --hostcall --trace prints it. */
+typedef struct modgpu_host_trace_event {
+    uint64_t t_ns;
+    int kind; /* MODGPU_TRACE_* */
+    int pipe;
+    uint64_t chunk, bytes;
+} modgpu_host_trace_event_t;
+enum {
+    MODGPU_TRACE_CALL_BEGIN = 0, MODGPU_TRACE_SLOTS = 1, MODGPU_TRACE_POSTED = 2, MODGPU_TRACE_PIPE_START = 3, MODGPU_TRACE_FILL_BEGIN = 4,
+    MODGPU_TRACE_FILL_END = 5, MODGPU_TRACE_LAUNCHED = 6, MODGPU_TRACE_SYNC_BEGIN = 7, MODGPU_TRACE_SYNC_END = 8, MODGPU_TRACE_DRAIN_END = 9,
+    MODGPU_TRACE_PIPE_END = 10, MODGPU_TRACE_CALL_END = 11
+};
+/* enable != 0 clears the buffer and starts recording (at most 2^20 events are kept); 0 stops. */
+void modgpu_host_trace(int enable);
+/* Copies the first min(cap, recorded) events to out (may be NULL with cap 0) and returns how many were recorded. */
+int modgpu_host_trace_read(modgpu_host_trace_event_t *out, int cap);
+/* The staging contexts' bookkeeping since load: out[0] = worker threads started (they park between calls and are never
+ * joined), out[1] = pipelines run by workers, out[2] = calls that had to wait for a slot, out[3] = host-buffer calls that began
+ * while another was in flight (any device), out[4] = slots per device. */
+void modgpu_host_pool_stats(uint64_t out[5]);
 
 /* modgpu_cycle_scalar_host with one named body ("generic", "avx2", "avx512"); MODGPU_ERR_INVALID if this CPU
  * does not run it.  Lets the tests compare every body with the oracle on one machine. */

@@ -71,6 +71,15 @@ class PathStats(ctypes.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class HostTraceEvent(ctypes.Structure):
+    """modgpu_host_trace_event_t (include/modgpu_testing.h)."""
+    _fields_ = [("t_ns", _u64), ("kind", _int), ("pipe", _int), ("chunk", _u64), ("bytes", _u64)]
+
+
+HOST_TRACE_KINDS = ("call_begin", "slots", "posted", "pipe_start", "fill_begin", "fill_end", "launched", "sync_begin", "sync_end",
+                    "drain_end", "pipe_end", "call_end")
+
+
 class LaunchInfo(ctypes.Structure):
     """modgpu_launch_info_t (include/modgpu_testing.h)."""
     _fields_ = [("kernel", ctypes.c_char_p), ("variant", _int), ("grid", ctypes.c_uint32), ("block", ctypes.c_uint32),
@@ -83,6 +92,10 @@ TESTING_EXPORTS = {
     "modgpu_last_launch": (_int, [ctypes.POINTER(LaunchInfo)]),
     "modgpu_kernel_source_hash": (ctypes.c_char_p, []),
     "modgpu_host_tunables": (None, [ctypes.POINTER(_u64)]),
+    "modgpu_host_chunking": (None, [ctypes.POINTER(_u64)]),
+    "modgpu_host_trace": (None, [_int]),
+    "modgpu_host_trace_read": (_int, [ctypes.POINTER(HostTraceEvent), _int]),
+    "modgpu_host_pool_stats": (None, [ctypes.POINTER(_u64)]),
     "modgpu_cycle_scalar_host_isa": (_int, [_vp, _u64, _i32, _u64, ctypes.c_char_p]),
     "modgpu_queue_stats": (None, [ctypes.POINTER(_u64)]),
     "modgpu_host_alloc_on_node": (_int, [ctypes.POINTER(_vp), _u64, _int]),
@@ -307,6 +320,32 @@ def host_tunables():
     out = (_u64 * 4)()
     lib().modgpu_host_tunables(out)
     return {"pipes": int(out[0]), "chunk_bytes": int(out[1]), "zerocopy_max_bytes": int(out[2]), "ring": int(out[3])}
+
+
+def host_chunking():
+    out = (_u64 * 2)()
+    lib().modgpu_host_chunking(out)
+    return {"split": int(out[0]), "chunk_min_bytes": int(out[1])}
+
+
+def host_trace(enable=True):
+    """Start (and clear) / stop the host-side timeline of the host-buffer and file routes."""
+    lib().modgpu_host_trace(1 if enable else 0)
+
+
+def host_trace_read():
+    """The recorded events as dicts, in recording order: t_ns, kind (HOST_TRACE_KINDS), pipe (-1: the call), chunk, bytes."""
+    n = lib().modgpu_host_trace_read(None, 0)
+    buf = (HostTraceEvent * max(n, 1))()
+    n = min(lib().modgpu_host_trace_read(buf, n), n)
+    return [{"t_ns": int(e.t_ns), "kind": HOST_TRACE_KINDS[e.kind], "pipe": e.pipe, "chunk": int(e.chunk), "bytes": int(e.bytes)} for e in buf[:n]]
+
+
+def host_pool_stats():
+    out = (_u64 * 5)()
+    lib().modgpu_host_pool_stats(out)
+    return {"workers_started": int(out[0]), "pipelines_run_by_workers": int(out[1]), "slot_waits": int(out[2]),
+            "calls_overlapped": int(out[3]), "slots_per_device": int(out[4])}
 
 
 def kernel_source_hash():

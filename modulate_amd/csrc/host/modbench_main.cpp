@@ -10,6 +10,11 @@
 //   modbench --hostcall
 //       modgpu_cycle_host (kernel) against modgpu_cycle_scalar_host (host loop) per call from 64 B to 2 MiB, and the
 //       crossover MODGPU_MIN_GPU_BYTES should sit at; per-core and all-core GB/s of every host-loop body.
+//   modbench --hostcall --trace
+//       the staged route's host-side timeline (modgpu_host_trace) for ONE call over a pageable buffer of 16 ... 256 MiB:
+//       when the slots were there, when each pipeline started, and per pipeline what its time went into -- filling slots
+//       (memcpy in), waiting for kernels, draining slots (memcpy out); full event list for the 64 MiB call.  Then two
+//       callers at once on one GPU (64 MiB each) against one caller alone.
 //   modbench --alloc
 //       what the part buffer costs: modgpu_host_alloc against modgpu_host_alloc_parts, and the kernel's rate on each.
 //   modbench --numa
@@ -206,6 +211,107 @@ int HostCall()
     return 0;
 }
 
+// ---- --hostcall --trace: where one staged call's time goes -----------------------------------------------
+int HostTrace()
+{
+    if( modgpu_device_count() < 1 ) { std::printf( "no HIP device\n" ); return 1; }
+    static const char* kKind[] = { "call_begin", "slots", "posted", "pipe_start", "fill_begin", "fill_end", "launched", "sync_begin", "sync_end", "drain_end", "pipe_end", "call_end" };
+    uint64_t tun[ 4 ], chk[ 2 ];
+    modgpu_host_tunables( tun );
+    modgpu_host_chunking( chk );
+    std::printf( "== staged route (pageable caller memory -> pinned slot -> kernel across PCIe on the slot -> back), one call traced per size\n" );
+    std::printf( "   pipelines <= %llu, slot <= %llu MiB, a buffer is cut into ~%llu chunks of >= %llu MiB\n", (unsigned long long)tun[ 0 ], (unsigned long long)( tun[ 1 ] >> 20 ),
+                 (unsigned long long)chk[ 0 ], (unsigned long long)( chk[ 1 ] >> 20 ) );
+    for( uint64_t mib : { 16ull, 32ull, 64ull, 128ull, 256ull } )
+    {
+        const uint64_t n = mib << 20;
+        std::vector< unsigned char > buf( n, 0x3C );
+        double best = 1e30;
+        for( int i = 0; i < 6; ++i ) { const double t0 = Now(); TRY( modgpu_cycle_host( buf.data(), n, kKey, 0, 0 ) ); best = std::min( best, Now() - t0 ); }
+        modgpu_host_trace( 1 );
+        const double t0 = Now();
+        TRY( modgpu_cycle_host( buf.data(), n, kKey, 0, 0 ) );
+        const double traced = Now() - t0;
+        modgpu_host_trace( 0 );
+        std::vector< modgpu_host_trace_event_t > ev( (size_t)modgpu_host_trace_read( nullptr, 0 ) );
+        modgpu_host_trace_read( ev.data(), (int)ev.size() );
+        if( ev.empty() ) continue;
+        const uint64_t z = ev.front().t_ns;
+        auto us = [ & ]( uint64_t t ) { return ( t - z ) * 1e-3; };
+        struct Pipe { double start = -1, end = 0, fill = 0, sync = 0, drain = 0, launch = 0, first_launch = -1; uint64_t chunks = 0; double t_fill = 0, t_sync = 0, t_launch = 0; };
+        std::vector< Pipe > pipes( 32 );
+        double slots_at = 0, posted_at = 0, end_at = 0, slot_bytes = 0;
+        uint64_t n_pipes = 0;
+        for( const auto& e : ev )
+        {
+            const double t = us( e.t_ns );
+            if( e.kind == MODGPU_TRACE_SLOTS ) { slots_at = t; n_pipes = e.chunk; slot_bytes = (double)e.bytes; }
+            if( e.kind == MODGPU_TRACE_POSTED ) posted_at = t;
+            if( e.kind == MODGPU_TRACE_CALL_END ) end_at = t;
+            if( e.pipe < 0 || e.pipe >= 32 ) continue;
+            Pipe& p = pipes[ (size_t)e.pipe ];
+            switch( e.kind )
+            {
+            case MODGPU_TRACE_PIPE_START: p.start = t; break;
+            case MODGPU_TRACE_FILL_BEGIN: p.t_fill = t; break;
+            case MODGPU_TRACE_FILL_END: p.fill += t - p.t_fill; p.t_launch = t; ++p.chunks; break;
+            case MODGPU_TRACE_LAUNCHED: p.launch += t - p.t_launch; if( p.first_launch < 0 ) p.first_launch = t; break;
+            case MODGPU_TRACE_SYNC_BEGIN: p.t_sync = t; break;
+            case MODGPU_TRACE_SYNC_END: p.sync += t - p.t_sync; p.t_fill = t; break;
+            case MODGPU_TRACE_DRAIN_END: p.drain += t - p.t_fill; break;
+            case MODGPU_TRACE_PIPE_END: p.end = t; break;
+            default: break;
+            }
+        }
+        std::printf( "-- %llu MiB: best of 6 %.3f ms = %.1f GB/s; the traced call %.3f ms; %llu pipelines, slots of %.1f MiB; slots there at %.0f us, pipelines posted at %.0f us, call ends at %.0f us\n",
+                     (unsigned long long)mib, best * 1e3, n / best / 1e9, traced * 1e3, (unsigned long long)n_pipes, slot_bytes / ( 1 << 20 ), slots_at, posted_at, end_at );
+        std::printf( "   pipe  start_us  first_launch_us  chunks  fill_us  launch_us  wait_for_kernel_us  drain_us   end_us  (fill + launch + wait + drain = busy)\n" );
+        double latest_start = 0, sum_fill = 0, sum_sync = 0, sum_drain = 0, sum_launch = 0;
+        for( size_t k = 0; k < pipes.size(); ++k )
+        {
+            const Pipe& p = pipes[ k ];
+            if( p.start < 0 ) continue;
+            latest_start = std::max( latest_start, p.start );
+            sum_fill += p.fill; sum_sync += p.sync; sum_drain += p.drain; sum_launch += p.launch;
+            std::printf( "   %4zu  %8.0f  %15.0f  %6llu  %7.0f  %9.0f  %18.0f  %8.0f  %7.0f\n", k, p.start, p.first_launch, (unsigned long long)p.chunks, p.fill, p.launch, p.sync, p.drain, p.end );
+        }
+        const double np_ = (double)std::max< uint64_t >( n_pipes, 1 );
+        std::printf( "   per pipeline on average: fill %.0f us, launch calls %.0f us, waiting for kernels %.0f us, drain %.0f us; last pipeline started at %.0f us;"
+                     " the link alone (50 GB/s each way) needs %.0f us\n", sum_fill / np_, sum_launch / np_, sum_sync / np_, sum_drain / np_, latest_start, n / 50e9 * 1e6 );
+        if( mib == 64 )
+        {
+            std::printf( "   every event of the 64 MiB call: t_us kind pipe chunk bytes\n" );
+            for( const auto& e : ev ) std::printf( "     %8.1f %-11s %3d %4llu %9llu\n", us( e.t_ns ), kKind[ e.kind ], e.pipe, (unsigned long long)e.chunk, (unsigned long long)e.bytes );
+        }
+    }
+    // two callers on ONE GPU at once (round 3 serialised them end to end on the device's staging mutex)
+    std::printf( "== concurrent callers on one GPU, pageable buffers, GB/s of payload summed over the callers (best of 5 rounds)\n" );
+    for( uint64_t mib : { 16ull, 64ull, 256ull } )
+    {
+        const uint64_t n = mib << 20;
+        for( int callers : { 1, 2, 4 } )
+        {
+            std::vector< std::vector< unsigned char > > bufs( (size_t)callers, std::vector< unsigned char >( n, 0x11 ) );
+            double best = 1e30;
+            for( int r = 0; r < 6; ++r )
+            {
+                const double t0 = Now();
+                std::vector< std::thread > ts;
+                for( int c = 1; c < callers; ++c ) ts.emplace_back( [ &, c ] { (void)modgpu_cycle_host( bufs[ (size_t)c ].data(), n, kKey, 0, 0 ); } );
+                (void)modgpu_cycle_host( bufs[ 0 ].data(), n, kKey, 0, 0 );
+                for( auto& t : ts ) t.join();
+                if( r > 0 ) best = std::min( best, Now() - t0 );
+            }
+            std::printf( "   %4llu MiB x %d caller%s: %7.3f ms  %6.1f GB/s\n", (unsigned long long)mib, callers, callers > 1 ? "s" : " ", best * 1e3, callers * (double)n / best / 1e9 );
+        }
+    }
+    uint64_t ps[ 5 ];
+    modgpu_host_pool_stats( ps );
+    std::printf( "   staging pool: %llu worker threads started in this process, %llu pipelines run by them, %llu waits for a slot, %llu calls began while another was in flight\n",
+                 (unsigned long long)ps[ 0 ], (unsigned long long)ps[ 1 ], (unsigned long long)ps[ 2 ], (unsigned long long)ps[ 3 ] );
+    return 0;
+}
+
 // ---- --files: the file routes beside their ceilings ---------------------------------------------------------------------
 // the library's chunking of a stream of n bytes (host_stream.cpp: stream_impl) at its default tunables
 void Schedule( uint64_t n, uint64_t* chunk, int* pipes )
@@ -399,6 +505,7 @@ int main( int argc, char** argv )
     std::vector< int > devices;
     std::vector< uint64_t > fileSizes;
     std::vector< const char* > positional;
+    bool trace = false;
     for( int i = 1; i < argc; ++i )
     {
         const std::string a = argv[ i ];
@@ -409,13 +516,14 @@ int main( int argc, char** argv )
         else if( a == "--steps" ) steps = std::atoi( next() );
         else if( a == "--warmup" ) warmup = std::atoi( next() );
         else if( a == "--hostcall" ) mode = "hostcall";
+        else if( a == "--trace" ) trace = true;
         else if( a == "--alloc" ) { mode = "alloc"; partBytes = 3291444381ull; nParts = 8; }
         else if( a == "--numa" ) { mode = "numa"; partBytes = 1ull << 30; }
         else if( a == "--files" ) { mode = "files"; dir = next(); }
         else if( a == "--bytes" ) fileSizes.push_back( std::strtoull( next(), nullptr, 0 ) );
         else positional.push_back( argv[ i ] );
     }
-    if( mode == "hostcall" ) return HostCall();
+    if( mode == "hostcall" ) return trace ? HostTrace() : HostCall();
     if( modgpu_device_count() < 1 ) { std::printf( "no HIP device\n" ); return 1; }
     if( mode == "parts" ) return nParts > 0 ? Parts( nParts, devices, partBytes, steps, std::max( warmup, 1 ) ) : 1;
     if( mode == "files" ) return Files( dir, fileSizes );

@@ -20,14 +20,28 @@
 //                     A file endpoint replaces its memcpy by pread / pwrite on the pinned slot.
 //   small (<= 1 MiB)  what the reference's three call sites pass (headers): no DMA submissions at
 //                     all, the kernel reads and writes pinned memory across PCIe itself.
+//
+// Who runs the pipelines (round 4).  A device's staging context owns a pool of slots and a pool of PARKED worker threads
+// (started on first use, bound to the GPU's NUMA node once, never joined).  A call takes the slots it needs from the pool
+// -- two callers on one GPU run side by side, each on its own slots; a call that finds too few free runs with fewer
+// pipelines, one that finds none waits for a release -- posts its pipelines to the workers and starts pipeline 0 itself
+// at once; workers and caller draw pipeline indices from the call until none is left.  Round 3 spawned (and bound, and
+// joined) seven std::threads per call and held one mutex per device for the length of the call: 0.2-0.3 ms of a 0.9-2.3 ms
+// call at 16-64 MiB, and concurrent callers ran strictly one after the other.  modgpu_host_trace (modgpu_testing.h) records
+// every step of a call with a timestamp; bin/modbench --hostcall --trace prints the timeline.
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <time.h>
+
 #include <algorithm>
 #include <cerrno>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -78,23 +92,88 @@ const int kPipes = env_int("MODGPU_HOST_PIPES", 8, 1, kMaxPipes);
 const uint64_t kChunk = (uint64_t)env_int("MODGPU_HOST_CHUNK_MB", 8, 1, 256) << 20;
 const uint64_t kZeroCopyMax = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_ZEROCOPY_KB", 1024, 0, 1 << 20) << 10, kChunk);
 const int kRing = env_int("MODGPU_HOST_RING", 4, 2, 4);
+//   MODGPU_HOST_SPLIT       a buffer is cut into about this many slots' worth of chunks ...
+//   MODGPU_HOST_CHUNK_MIN_MB  ... of at least this many MiB (and at most MODGPU_HOST_CHUNK_MB)
+const uint64_t kSplit = (uint64_t)env_int("MODGPU_HOST_SPLIT", 16, 2, 256);
+const uint64_t kChunkMin = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_CHUNK_MIN_MB", 4, 1, 256) << 20, kChunk);
 
+// ---- host-side timeline of the staged / pinned routes (modgpu_host_trace, reporting only) --------------------------------
+std::atomic<bool> g_trace_on{false};
+std::mutex g_trace_mu;
+std::vector<modgpu_host_trace_event_t> g_trace;
+inline void trace(int kind, int pipe, uint64_t chunk, uint64_t bytes)
+{
+    if (!g_trace_on.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lock(g_trace_mu);
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts); // (read under the lock: the log is in time order)
+    if (g_trace.size() < (1u << 20)) g_trace.push_back({(uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec, kind, pipe, chunk, bytes});
+}
+
+struct Call;
+// One per logical device, allocated once and never destroyed (parked workers wait on its condition variable for the life of
+// the process).  `mu` guards the slot ownership table and the work queue; a slot's buffers and stream are touched only by the
+// call that owns the slot.
 struct Staging {
     std::mutex mu;
+    std::condition_variable slot_cv; // a call gave slots back
+    std::condition_variable work_cv; // a call posted pipelines
     uint8_t *pinned[kSlots] = {};
     uint8_t *dev[kSlots] = {};
     hipStream_t stream[kSlots] = {};
     uint64_t pinned_cap[kSlots] = {};
     uint64_t dev_cap[kSlots] = {};
+    bool busy[kSlots] = {};                     // under mu
+    std::deque<std::shared_ptr<Call>> requests; // under mu: one entry per pipeline a call would like a worker for
+    int workers = 0, parked = 0;                // under mu
 };
-Staging g_staging[kMaxDevices];
+Staging *const g_staging = new Staging[kMaxDevices];
+std::atomic<uint64_t> g_pool_spawned{0}, g_pool_tasks{0}, g_slot_waits{0}, g_calls_in_flight{0}, g_calls_overlapped{0};
 
-// Slots [first, first + count) get a stream, `need` device bytes and -- if want_pinned -- `need`
-// pinned bytes each (grown on demand, never shrunk).  `need` is clamped to [1 MiB, kChunk].
-int staging_reserve(Staging &s, int first, int count, uint64_t need, bool want_dev, bool want_pinned)
+// Slots a call owns, given back (and waiters woken) when the call ends, whichever way.
+struct SlotLease {
+    Staging &s;
+    std::vector<int> ids;
+    explicit SlotLease(Staging &st) : s(st) {}
+    SlotLease(const SlotLease &) = delete;
+    SlotLease &operator=(const SlotLease &) = delete;
+    // takes up to `want` slots in whole groups of `group`; waits while fewer than one group is free
+    void acquire(int want, int group)
+    {
+        std::unique_lock<std::mutex> lock(s.mu);
+        auto n_free = [&] {
+            int f = 0;
+            for (int i = 0; i < kSlots; ++i) f += s.busy[i] ? 0 : 1;
+            return f;
+        };
+        if (n_free() < group) {
+            g_slot_waits.fetch_add(1, std::memory_order_relaxed);
+            s.slot_cv.wait(lock, [&] { return n_free() >= group; });
+        }
+        const int take = std::min(want, n_free()) / group * group;
+        for (int i = 0; i < kSlots && (int)ids.size() < take; ++i)
+            if (!s.busy[i]) {
+                s.busy[i] = true;
+                ids.push_back(i);
+            }
+    }
+    ~SlotLease()
+    {
+        if (ids.empty()) return;
+        {
+            std::lock_guard<std::mutex> lock(s.mu);
+            for (int i : ids) s.busy[i] = false;
+        }
+        s.slot_cv.notify_all();
+    }
+};
+
+// The slots of a lease get a stream, `need` device bytes and -- if want_pinned -- `need` pinned bytes each (grown on
+// demand, never shrunk).  `need` is clamped to [1 MiB, kChunk].  Only the owner of a slot touches it: no lock.
+int staging_reserve(Staging &s, const std::vector<int> &ids, uint64_t need, bool want_dev, bool want_pinned)
 {
     need = std::min<uint64_t>(std::max<uint64_t>(need, 1ull << 20), kChunk);
-    for (int i = first; i < first + count; ++i) {
+    for (int i : ids) {
         if (!s.stream[i]) HIP_TRY(hipStreamCreateWithFlags(&s.stream[i], hipStreamNonBlocking));
         if (want_pinned && s.pinned_cap[i] < need) {
             if (s.pinned[i]) HIP_TRY(hipHostFree(s.pinned[i]));
@@ -157,10 +236,12 @@ struct Job {
     std::atomic<bool> touched{false};
 };
 
-// One pipeline: chunks first, first+stride, ... of the stream through slots [slot0, slot0+ring).
+// One pipeline: chunks first, first+stride, ... of the stream through the `ring` slots slots[0..ring).
 // A pinned memory endpoint is DMA'd directly; anything else passes through the slot's pinned buffer.
-int run_pipe(Staging &s, int slot0, int ring, Job &j, uint64_t first, uint64_t stride)
+int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uint64_t stride)
 {
+    const int pipe = (int)first;
+    trace(MODGPU_TRACE_PIPE_START, pipe, 0, 0);
     const uint64_t n_chunks = (j.n + j.chunk - 1) / j.chunk;
     const bool src_direct = j.src.mem && j.src.pinned, dst_direct = j.dst.mem && j.dst.pinned;
     auto span = [&](uint64_t c, uint64_t *off, uint64_t *len) {
@@ -169,34 +250,46 @@ int run_pipe(Staging &s, int slot0, int ring, Job &j, uint64_t first, uint64_t s
     };
     const uint64_t mine = first < n_chunks ? (n_chunks - first + stride - 1) / stride : 0;
     auto step = [&](uint64_t i) -> int {
-        const int slot = slot0 + (int)(i % (uint64_t)ring);
+        const int slot = slots[i % (uint64_t)ring];
         if (i >= (uint64_t)ring) { // retire the chunk that used this slot `ring` trips ago
             uint64_t off, len;
-            span(first + (i - ring) * stride, &off, &len);
+            const uint64_t c = first + (i - ring) * stride;
+            span(c, &off, &len);
+            trace(MODGPU_TRACE_SYNC_BEGIN, pipe, c, len);
             HIP_TRY(hipStreamSynchronize(s.stream[slot]));
+            trace(MODGPU_TRACE_SYNC_END, pipe, c, len);
             if (!dst_direct && !j.in_dst) {
                 j.touched.store(true, std::memory_order_relaxed);
                 int rc = drain_slot(j.dst, s.pinned[slot], off, len);
+                trace(MODGPU_TRACE_DRAIN_END, pipe, c, len);
                 if (rc) return rc;
             }
         }
         if (i < mine) {
             uint64_t off, len;
-            span(first + i * stride, &off, &len);
+            const uint64_t c = first + i * stride;
+            span(c, &off, &len);
+            trace(MODGPU_TRACE_FILL_BEGIN, pipe, c, len);
             if (j.in_dst) {
                 j.touched.store(true, std::memory_order_relaxed);
                 int rc = fill_slot(j.src, j.dst.mem + off, off, len);
                 if (rc) return rc;
+                trace(MODGPU_TRACE_FILL_END, pipe, c, len);
                 void *mapped = nullptr;
                 HIP_TRY(hipHostGetDevicePointer(&mapped, j.dst.mem + off, 0));
-                return cycle_device_impl(mapped, len, j.key, j.stream_off + off, s.stream[slot], /*over_pcie=*/true);
+                rc = cycle_device_impl(mapped, len, j.key, j.stream_off + off, s.stream[slot], /*over_pcie=*/true);
+                trace(MODGPU_TRACE_LAUNCHED, pipe, c, len);
+                return rc;
             }
             if (j.slot_kernel) { // neither side is pinned caller memory: the slot itself is the device-visible copy
                 int rc = fill_slot(j.src, s.pinned[slot], off, len);
                 if (rc) return rc;
+                trace(MODGPU_TRACE_FILL_END, pipe, c, len);
                 void *mapped = nullptr;
                 HIP_TRY(hipHostGetDevicePointer(&mapped, s.pinned[slot], 0));
-                return cycle_device_impl(mapped, len, j.key, j.stream_off + off, s.stream[slot], /*over_pcie=*/true);
+                rc = cycle_device_impl(mapped, len, j.key, j.stream_off + off, s.stream[slot], /*over_pcie=*/true);
+                trace(MODGPU_TRACE_LAUNCHED, pipe, c, len);
+                return rc;
             }
             if (src_direct) {
                 HIP_TRY(hipMemcpyAsync(s.dev[slot], j.src.mem + off, len, hipMemcpyHostToDevice, s.stream[slot]));
@@ -205,8 +298,10 @@ int run_pipe(Staging &s, int slot0, int ring, Job &j, uint64_t first, uint64_t s
                 if (rc) return rc;
                 HIP_TRY(hipMemcpyAsync(s.dev[slot], s.pinned[slot], len, hipMemcpyHostToDevice, s.stream[slot]));
             }
+            trace(MODGPU_TRACE_FILL_END, pipe, c, len);
             int rc = cycle_device_impl(s.dev[slot], len, j.key, j.stream_off + off, s.stream[slot]);
             if (rc) return rc;
+            trace(MODGPU_TRACE_LAUNCHED, pipe, c, len);
             if (dst_direct) {
                 j.touched.store(true, std::memory_order_relaxed);
                 HIP_TRY(hipMemcpyAsync(j.dst.mem + off, s.dev[slot], len, hipMemcpyDeviceToHost, s.stream[slot]));
@@ -220,11 +315,86 @@ int run_pipe(Staging &s, int slot0, int ring, Job &j, uint64_t first, uint64_t s
     for (uint64_t i = 0; i < mine + (uint64_t)ring && rc == MODGPU_OK; ++i) rc = step(i);
     if (rc != MODGPU_OK) { // nothing of this call may still be running against the caller's memory once we return
         const std::string keep = t_err;
-        for (int k = 0; k < ring; ++k) (void)hipStreamSynchronize(s.stream[slot0 + k]);
+        for (int k = 0; k < ring; ++k) (void)hipStreamSynchronize(s.stream[slots[k]]);
         (void)hipGetLastError();
         t_err = keep;
     }
+    trace(MODGPU_TRACE_PIPE_END, pipe, 0, 0);
     return rc;
+}
+
+// ---- a call's pipelines, drawn by the caller and by parked workers ---------------------------------------------------------
+struct Call {
+    Staging &s;
+    Job &job; // (lives on the caller's stack: touched only while a pipeline index is held, and the caller waits for those)
+    const int pipes, ring, phys;
+    std::vector<int> slots; // pipes * ring slot ids
+    std::atomic<int> next{0};
+    std::mutex mu;
+    std::condition_variable cv;
+    int finished = 0; // under mu
+    std::vector<int> rcs;
+    std::vector<std::string> errs;
+    Call(Staging &st, Job &j, int p, int r, int ph, std::vector<int> ids) : s(st), job(j), pipes(p), ring(r), phys(ph), slots(std::move(ids)), rcs((size_t)p, MODGPU_OK), errs((size_t)p) {}
+    // runs pipelines until none is left to start
+    void help(bool worker)
+    {
+        for (;;) {
+            const int p = next.fetch_add(1, std::memory_order_relaxed);
+            if (p >= pipes) return;
+            if (worker) g_pool_tasks.fetch_add(1, std::memory_order_relaxed);
+            rcs[(size_t)p] = run_pipe(s, &slots[(size_t)p * (size_t)ring], ring, job, (uint64_t)p, (uint64_t)pipes);
+            if (rcs[(size_t)p]) errs[(size_t)p] = t_err;
+            std::lock_guard<std::mutex> lock(mu);
+            if (++finished == pipes) cv.notify_all();
+        }
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&] { return finished == pipes; });
+    }
+};
+
+// A parked worker: bound to its GPU's NUMA node and HIP device once, then serves whatever calls post.
+void worker_main(Staging *s, int logical, int phys)
+{
+    run_near_device(logical); // a staging worker's memcpys run on the socket its GPU hangs off
+    (void)hipSetDevice(phys); // HIP's current device is per thread
+    std::unique_lock<std::mutex> lock(s->mu);
+    for (;;) {
+        ++s->parked;
+        s->work_cv.wait(lock, [&] { return !s->requests.empty(); });
+        --s->parked;
+        std::shared_ptr<Call> call = std::move(s->requests.front());
+        s->requests.pop_front();
+        lock.unlock();
+        call->help(true);
+        call.reset();
+        lock.lock();
+    }
+}
+
+// Posts `extra` pipelines of `call` to the device's workers, starting workers the pool is short of (never more than
+// kMaxPipes - 1 per device; if a thread cannot be started the caller simply runs more of the pipelines itself).
+void post_to_workers(Staging &s, const std::shared_ptr<Call> &call, int extra, int logical)
+{
+    if (extra <= 0) return;
+    {
+        std::lock_guard<std::mutex> lock(s.mu);
+        for (int k = 0; k < extra; ++k) s.requests.push_back(call);
+        const int short_of = (int)s.requests.size() - s.parked;
+        for (int k = 0; k < short_of && s.workers < kMaxPipes - 1; ++k) {
+            try {
+                std::thread(worker_main, &s, logical, call->phys).detach();
+                ++s.workers;
+                g_pool_spawned.fetch_add(1, std::memory_order_relaxed);
+            } catch (...) {
+                break;
+            }
+        }
+    }
+    s.work_cv.notify_all();
 }
 
 } // namespace
@@ -248,7 +418,12 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     if (identity && in_place) return MODGPU_OK;
     if (dev >= kMaxDevices) return fail(MODGPU_ERR_INVALID, "device index beyond staging table");
     Staging &s = g_staging[dev];
-    std::lock_guard<std::mutex> lock(s.mu);
+    struct InFlight { // (reporting: did host-buffer calls ever overlap on a GPU?  modgpu_host_pool_stats)
+        InFlight() { if (g_calls_in_flight.fetch_add(1, std::memory_order_relaxed) > 0) g_calls_overlapped.fetch_add(1, std::memory_order_relaxed); }
+        ~InFlight() { g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+    } in_flight;
+    trace(MODGPU_TRACE_CALL_BEGIN, -1, 0, n);
+    struct CallEnd { uint64_t n; ~CallEnd() { trace(MODGPU_TRACE_CALL_END, -1, 0, n); } } call_end{n};
 
     const bool src_direct = src.mem && src.pinned, dst_direct = dst.mem && dst.pinned;
     const bool all_direct = (!src.mem || src_direct) && (!dst.mem || dst_direct);
@@ -265,39 +440,45 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     //  30 for the staged route, profiles/r02_sweep_pinned_routes.txt; mode 1 keeps the DMA ring selectable)
     const int mode = pinned_mode();
     if (in_place && src_direct && !identity && (n <= kZeroCopyMax || mode != 1)) {
-        rc = staging_reserve(s, 0, 1, 0, false, false);
+        SlotLease lease(s);
+        lease.acquire(1, 1);
+        const int slot = lease.ids[0];
+        rc = staging_reserve(s, lease.ids, 0, false, false);
         if (rc) return rc;
         void *mapped = nullptr;
         HIP_TRY(hipHostGetDevicePointer(&mapped, src.mem, 0));
-        rc = cycle_device_impl(mapped, n, key, stream_off, s.stream[0], /*over_pcie=*/true);
+        rc = cycle_device_impl(mapped, n, key, stream_off, s.stream[slot], /*over_pcie=*/true);
         if (rc) return rc; // nothing was launched: the caller's pages are as they were
         if (touched) *touched = true;
-        hipError_t e = hipStreamSynchronize(s.stream[0]);
+        hipError_t e = hipStreamSynchronize(s.stream[slot]);
         if (e != hipSuccess) return fail_hip(e, "hipStreamSynchronize (kernel over PCIe)");
         account();
         return MODGPU_OK;
     }
     if (n <= kZeroCopyMax && src.mem && dst.mem && !identity) {
-        rc = staging_reserve(s, 0, 1, n, false, true);
+        SlotLease lease(s);
+        lease.acquire(1, 1);
+        const int slot = lease.ids[0];
+        rc = staging_reserve(s, lease.ids, n, false, true);
         if (rc) return rc;
-        if (s.pinned_cap[0] < n) return fail(MODGPU_ERR_INVALID, "staging slot smaller than the zero-copy buffer");
+        if (s.pinned_cap[slot] < n) return fail(MODGPU_ERR_INVALID, "staging slot smaller than the zero-copy buffer");
         void *mapped = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(&mapped, s.pinned[0], 0));
-        std::memcpy(s.pinned[0], src.mem, n);
-        rc = cycle_device_impl(mapped, n, key, stream_off, s.stream[0], /*over_pcie=*/true);
-        hipError_t e = hipStreamSynchronize(s.stream[0]);
+        HIP_TRY(hipHostGetDevicePointer(&mapped, s.pinned[slot], 0));
+        std::memcpy(s.pinned[slot], src.mem, n);
+        rc = cycle_device_impl(mapped, n, key, stream_off, s.stream[slot], /*over_pcie=*/true);
+        hipError_t e = hipStreamSynchronize(s.stream[slot]);
         if (rc) return rc;
         if (e != hipSuccess) return fail_hip(e, "hipStreamSynchronize (kernel over PCIe)");
         if (touched) *touched = true;
-        std::memcpy(dst.mem, s.pinned[0], n);
+        std::memcpy(dst.mem, s.pinned[slot], n);
         account();
         return MODGPU_OK;
     }
 
     // slot size: the whole buffer if it is small, else ~n/16 between 4 MiB and the cap (8 MiB by default:
     // profiles/r02_sweep_staged_routes.txt)
-    uint64_t chunk = n <= (4ull << 20) ? std::max<uint64_t>(n, 1ull << 20)
-                                       : std::min<uint64_t>(kChunk, std::max<uint64_t>(4ull << 20, ((n >> 4) + 0xFFFFF) & ~0xFFFFFull));
+    uint64_t chunk = n <= kChunkMin ? std::max<uint64_t>(n, 1ull << 20)
+                                    : std::min<uint64_t>(kChunk, std::max<uint64_t>(kChunkMin, ((n / kSplit) + 0xFFFFF) & ~0xFFFFFull));
     chunk = std::min<uint64_t>(chunk, kChunk);
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
     Job job{src, dst, n, chunk, key, stream_off};
@@ -318,38 +499,27 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     // a destination file gets its blocks before eight threads write into it at once (tmpfs and most file systems
     // allocate under one lock: parallel extending writes serialise there)
     if (dst.fd >= 0 && n >= (8ull << 20)) (void)::posix_fallocate(dst.fd, (off_t)dst.base, (off_t)n);
-    rc = staging_reserve(s, 0, pipes * ring, chunk, !job.slot_kernel && !job.in_dst, !(src_direct && dst_direct) && !job.in_dst);
+    // this call's slots: what it would like, or as many whole pipelines as are free right now (another caller may be at work
+    // on this GPU), at least one
+    SlotLease lease(s);
+    lease.acquire(pipes * ring, ring);
+    pipes = (int)lease.ids.size() / ring;
+    trace(MODGPU_TRACE_SLOTS, -1, (uint64_t)pipes, chunk);
+    rc = staging_reserve(s, lease.ids, chunk, !job.slot_kernel && !job.in_dst, !(src_direct && dst_direct) && !job.in_dst);
     if (rc) return rc;
 
     if (pipes <= 1) {
-        rc = run_pipe(s, 0, ring, job, 0, 1);
+        rc = run_pipe(s, lease.ids.data(), ring, job, 0, 1);
     } else {
-        std::vector<int> rcs((size_t)pipes, MODGPU_OK);
-        std::vector<std::string> errs((size_t)pipes);
-        std::vector<std::thread> workers;
-        const int phys = physical_of(dev);
-        auto body = [&](int p, bool own_thread) {
-            if (own_thread) run_near_device(dev); // a staging worker's memcpys run on the socket its GPU hangs off
-            if (hipSetDevice(phys) != hipSuccess) { // HIP's current device is per thread
-                rcs[p] = MODGPU_ERR_HIP;
-                errs[p] = "hipSetDevice in staging worker";
-                return;
-            }
-            rcs[p] = run_pipe(s, p * ring, ring, job, (uint64_t)p, (uint64_t)pipes);
-            if (rcs[p]) errs[p] = t_err;
-        };
-        int started = 1; // pipeline 0 runs on the calling thread
-        try {
-            for (int p = 1; p < pipes; ++p, ++started) workers.emplace_back(body, p, true);
-        } catch (...) { // thread limit: the pipelines that did not get a thread run here, one after another
-        }
-        body(0, false);
-        for (int p = started; p < pipes; ++p) body(p, false);
-        for (auto &w : workers) w.join();
+        auto call = std::make_shared<Call>(s, job, pipes, ring, physical_of(dev), lease.ids);
+        post_to_workers(s, call, pipes - 1, dev);
+        trace(MODGPU_TRACE_POSTED, -1, (uint64_t)pipes, 0);
+        call->help(false); // pipeline 0 starts now, on the calling thread; then whatever no worker has picked up yet
+        call->wait();
         for (int p = 0; p < pipes && rc == MODGPU_OK; ++p)
-            if (rcs[p]) {
-                t_err = errs[p];
-                rc = rcs[p];
+            if (call->rcs[(size_t)p]) {
+                t_err = call->errs[(size_t)p];
+                rc = call->rcs[(size_t)p];
             }
     }
     if (touched) *touched = job.touched.load();
@@ -374,6 +544,39 @@ extern "C" {
 #ifdef MODGPU_TESTING_HOOKS
 void modgpu_debug_inject_failures(int count) { g_inject_failures.store(count > 0 ? count : 0); }
 #endif
+
+void modgpu_host_trace(int enable)
+{
+    if (enable) {
+        std::lock_guard<std::mutex> lock(g_trace_mu);
+        g_trace.clear();
+        g_trace.reserve(1u << 16);
+    }
+    g_trace_on.store(enable != 0, std::memory_order_relaxed);
+}
+
+int modgpu_host_trace_read(modgpu_host_trace_event_t *out, int cap)
+{
+    std::lock_guard<std::mutex> lock(g_trace_mu);
+    const int n = (int)std::min<size_t>(g_trace.size(), (size_t)(cap > 0 ? cap : 0));
+    if (out && n > 0) std::memcpy(out, g_trace.data(), (size_t)n * sizeof(modgpu_host_trace_event_t));
+    return (int)g_trace.size();
+}
+
+void modgpu_host_pool_stats(uint64_t out[5])
+{
+    out[0] = g_pool_spawned.load();
+    out[1] = g_pool_tasks.load();
+    out[2] = g_slot_waits.load();
+    out[3] = g_calls_overlapped.load();
+    out[4] = (uint64_t)kSlots;
+}
+
+void modgpu_host_chunking(uint64_t out[2])
+{
+    out[0] = kSplit;
+    out[1] = kChunkMin;
+}
 
 void modgpu_host_tunables(uint64_t out[4])
 {

@@ -188,6 +188,45 @@ def test_staged_pipelines_and_routes(hooks):
     assert M.lib().modgpu_host_free(buf.ctypes.data) == 1 and M.lib().modgpu_host_unregister(buf.ctypes.data) == 1
 
 
+def test_concurrent_callers_share_one_device_and_the_parked_workers(hooks):
+    """Round 4: a device's staging context hands SLOTS to calls instead of holding one mutex for a whole call, and its
+    pipelines run on parked worker threads instead of threads spawned per call.  Four threads call modgpu_cycle_host on
+    ONE device at once, pageable and pinned buffers mixed, several rounds: bytes exact, the calls really overlapped, no
+    more than 15 workers were ever started for the device, and with 32 slots and 16 wanted per staged call the third
+    and fourth caller had to take fewer pipelines or wait (both paths run).  The timeline hook records while this happens."""
+    M.host_trace(True)
+    before = M.host_pool_stats()
+    sizes = [(5 << 20) + 3, (9 << 20) + 1, (3 << 20) + 7, (12 << 20) + 5]
+    errors = []
+
+    def caller(i):
+        try:
+            for r in range(3):
+                pt = O.splitmix_bytes(sizes[i], 10 * i + r)
+                got = M.cycle_host(pt.copy(), M.KEY_PS4, stream_off=i, device=2)
+                assert np.array_equal(got, want(pt, M.KEY_PS4, i)), (i, r)
+                small = O.splitmix_bytes(70_000 + i, r)  # the one-slot route in between
+                assert np.array_equal(M.cycle_host(small.copy(), M.KEY_PS3, device=2), want(small, M.KEY_PS3))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=caller, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    M.host_trace(False)
+    assert not errors, errors
+    after = M.host_pool_stats()
+    assert after["calls_overlapped"] > before["calls_overlapped"]
+    assert after["pipelines_run_by_workers"] > before["pipelines_run_by_workers"]
+    assert 0 < after["workers_started"] - before["workers_started"] <= 15
+    ev = M.host_trace_read()
+    kinds = {e["kind"] for e in ev}
+    assert {"call_begin", "slots", "posted", "pipe_start", "fill_begin", "fill_end", "launched", "sync_begin", "sync_end", "drain_end",
+            "pipe_end", "call_end"} <= kinds
+    assert sum(e["kind"] == "call_begin" for e in ev) == sum(e["kind"] == "call_end" for e in ev) == 24
+    assert all(b["t_ns"] >= a["t_ns"] for a, b in zip(ev, ev[1:]))  # recorded under one lock: monotonic
+
+
 def test_file_routes_and_their_error_paths(hooks, tmp_path):
     for n in (0, 1, (2 << 20) + 3, (9 << 20) + 11):
         pt = O.splitmix_bytes(n, n + 3)

@@ -327,6 +327,100 @@ def test_config5_eight_workers_aliased(host, oracle, tmp_path, header_cwd):
     b.close()
 
 
+def _fast_tree_digest(root):
+    """relative path -> (size, 128-bit digest) of every file under root (xxh3 when the module is there: 20 GB are hashed)."""
+    try:
+        import xxhash
+        h = lambda b: xxhash.xxh3_128(b).hexdigest()  # noqa: E731
+    except ImportError:  # pragma: no cover
+        import hashlib
+        h = lambda b: hashlib.blake2b(b, digest_size=16).hexdigest()  # noqa: E731
+    out = {}
+    for r, _, fs in os.walk(root):
+        for f in fs:
+            p = os.path.join(r, f)
+            b = np.fromfile(p, dtype=np.uint8)
+            out[os.path.relpath(p, root)] = (b.size, h(b.tobytes() if b.size < (1 << 20) else memoryview(b)))
+    return out
+
+
+def test_config5_full_scale_eight_workers_one_worker_and_the_cpu_path(host, oracle, modgpu, tmp_path, header_cwd):
+    """BASELINE config 5 -- decrypt -> unpack -> repack -> encrypt, "byte-diff vs the build's CPU path" -- at config 4's
+    stated scale: 100 000 entries, 3.29 GB, 8 parts of ~411 MB (CArk.cpp:424-504, 760-828, 845-899,
+    Modulate.cpp:291-317, 380-450).  Through the CLI, three times:
+        gpu8   -cryptparts -gpus 8 under MODGPU_DEVICE_ALIAS=8: eight worker threads, eight staging contexts, eight file
+               pipelines of 50+ chunks each at once, fallocate + parallel pwrite -- the 8-GPU form on this box's one GPU
+        gpu1   one worker
+        cpu    no GPU visible to the child, MODGPU_REQUIRE_GPU=0: the library's host loop does the part cipher
+    Every extracted file must equal its source bytes; the repacked header must equal the independent Python restatement
+    encrypted by the oracle (bytes 12..27 masked: undefined upstream); every ~411 MB part must oracle-decrypt to
+    bytes that hold every file at its header offset; and the three runs' outputs must be identical byte for byte."""
+    import shutil
+    host.select_platform(True)
+    names, sizes, data = synth_100k()
+    offs = np.cumsum([0] + sizes)
+    first = str(tmp_path / "first") + "/"
+    os.makedirs(first)
+    a = host.Ark()
+    a.construct_from_table(names, sizes, 8, "main_ps4")
+    a.build_from_memory(data)
+    a.enable_part_cipher(True, 1)
+    a.save(first, "main_ps4.hdr")
+    assert min(a.ark_sizes()) > (350 << 20)
+    a.close()
+    base = {k: v for k, v in os.environ.items() if k not in ("MODGPU_DEVICE_ALIAS", "MODGPU_REQUIRE_GPU")}
+    runs = {
+        "gpu8": (dict(base, MODGPU_DEVICE_ALIAS="8", MODGPU_REQUIRE_GPU="1"), "8"),
+        "gpu1": (dict(base, MODGPU_REQUIRE_GPU="1"), "1"),
+        "cpu": (dict(base, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1", MODGPU_REQUIRE_GPU="0"), "8"),
+    }
+    digests = {}
+    for tag, (env, gpus) in runs.items():
+        unpacked, packed = str(tmp_path / f"u_{tag}"), str(tmp_path / f"p_{tag}")
+        os.makedirs(packed)
+        r = subprocess.run([EXE, "-cryptparts", "-gpus", gpus, "-unpack", first, unpacked], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0 and "Complete!" in r.stdout, tag + r.stdout[-2000:] + r.stderr[-2000:]
+        if tag == "gpu8":  # every extracted file == its source bytes (100 000 files)
+            for nm, s_, o in zip(names, sizes, offs):
+                got = np.fromfile(os.path.join(unpacked, nm), dtype=np.uint8)
+                assert got.size == s_ and np.array_equal(got, data[o:o + s_]), nm
+        r = subprocess.run([EXE, "-cryptparts", "-gpus", gpus, "-pack", first, unpacked, packed], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0 and "Complete!" in r.stdout, tag + r.stdout[-2000:] + r.stderr[-2000:]
+        digests[tag] = (_fast_tree_digest(unpacked), _fast_tree_digest(packed))
+        assert len(digests[tag][0]) == 100_000 and len(digests[tag][1]) == 9
+        shutil.rmtree(unpacked)
+        if tag != "gpu8":
+            shutil.rmtree(packed)
+    assert digests["gpu8"] == digests["gpu1"], "8 workers and 1 worker wrote different bytes"
+    assert digests["gpu8"] == digests["cpu"], "the GPU path and the build's CPU path wrote different bytes"
+    # the repacked archive of the 8-worker run, against the restatement and the oracle
+    p8 = str(tmp_path / "p_gpu8") + "/"
+    b = host.Ark().load(p8 + "main_ps4.hdr")
+    files = b.files()
+    assert sorted(f["name"] for f in files) == sorted(names)
+    plain = AH.serialise([f["name"] for f in files], [f["size"] for f in files], [f["offset"] for f in files], b.ark_sizes(), b.ark_paths(), True,
+                         flags1=[f["flags1"] for f in files], flags2=[f["flags2"] for f in files])
+    want = np.frombuffer(plain, dtype=np.uint8).copy()
+    assert oracle.hdr_encrypt(want, True) == 0
+    disk = np.fromfile(p8 + "main_ps4.hdr", dtype=np.uint8)
+    assert disk.size == want.size and disk.size > (4 << 20)
+    # bytes 12..27 of the PLAINTEXT are undefined upstream; the cipher is bytewise, so they are bytes 12..27 of the image too
+    mask = np.ones(disk.size, dtype=bool)
+    mask[12:28] = False
+    assert np.array_equal(disk[mask], want[mask])
+    raw = []
+    for path, size in zip(b.ark_paths(), b.ark_sizes()):
+        part = np.fromfile(p8 + path, dtype=np.uint8)
+        assert part.size == size and size > (350 << 20)
+        raw.append(oracle.cycle(part, oracle.KEY_PS4))  # decrypt on the CPU
+    raw = np.concatenate(raw)
+    by_name = dict(zip(names, zip(offs, sizes)))
+    for f in files:
+        o, s_ = by_name[f["name"]]
+        assert f["size"] == s_ and np.array_equal(raw[f["offset"]:f["offset"] + s_], data[o:o + s_]), f["name"]
+    b.close()
+
+
 def test_bench_two_ranks_rehearsal(host, tmp_path):
     """The driver's N>1 launch line (torch.distributed.run, one rank per GPU) rehearsed with 2 ranks on this
     box's one GPU: gloo for the barrier / MAX (RCCL wants one GPU per rank), both ranks on device 0.

@@ -19,5 +19,8 @@ tail)         # profiles/r04_tail.txt: where a sub-GiB launch's time goes, and t
     timeout -k 10 400 tools/tune_cycle 4294967296 3 > $O/r04_tune_4GiB.txt ;;
 memside)      # profiles/r04_memside_counters.json
     bash tools/memside_counters.sh 4294967296 ;;
-*) echo "usage: tools/reproduce_r04.sh build | tail | memside" ;;
+staged)       # profiles/r04_staged_midsize.txt
+    modulate_amd/bin/modbench --hostcall --trace > $O/r04_hostcall_trace.txt
+    python3 tools/sweep_midsize_host.py > $O/r04_sweep_midsize_host.txt ;;
+*) echo "usage: tools/reproduce_r04.sh build | tail | memside | staged" ;;
 esac

@@ -23,11 +23,10 @@ for mib in (16, 32, 64, 128, 256):
     out.append("%%6.2f ms %%5.1f GB/s" %% (best * 1e3, n / best / 1e9))
 print(" | ".join(out))
 """
-print("%-34s | " % "setting" + " | ".join("%3d MiB            " % m for m in (16, 32, 64, 128, 256)))
-for chunk in (None, 1, 2, 4):
-    for pipes in (8, 16):
-        env = dict(os.environ, MODGPU_REQUIRE_GPU="1", MODGPU_HOST_PIPES=str(pipes))
-        if chunk:
-            env["MODGPU_HOST_CHUNK_MB"] = str(chunk)
-        r = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, env=env, timeout=600)
-        print("%-34s | %s" % ("slot <= %s MiB, %2d pipelines" % (chunk or "8 (default)", pipes), r.stdout.strip() or r.stderr[-300:]), flush=True)
+print("%-44s | " % "setting" + " | ".join("%3d MiB            " % m for m in (16, 32, 64, 128, 256)))
+# (split, smallest chunk MiB, pipelines): a buffer is cut into ~split chunks of at least that size (and at most MODGPU_HOST_CHUNK_MB = 8)
+for split, cmin, pipes in ((16, 4, 8), (16, 2, 8), (16, 1, 8), (32, 2, 8), (32, 1, 8), (64, 1, 8), (32, 2, 16), (32, 1, 16), (64, 1, 16), (16, 4, 4), (32, 2, 4)):
+    env = dict(os.environ, MODGPU_REQUIRE_GPU="1", MODGPU_HOST_PIPES=str(pipes), MODGPU_HOST_SPLIT=str(split), MODGPU_HOST_CHUNK_MIN_MB=str(cmin))
+    r = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, env=env, timeout=600)
+    print("%-44s | %s" % ("~%d chunks of >= %d MiB, %2d pipelines%s" % (split, cmin, pipes, "  (default)" if (split, cmin, pipes) == (16, 4, 8) else ""),
+                          r.stdout.strip() or r.stderr[-300:]), flush=True)
