@@ -44,6 +44,10 @@
  *     MODGPU_REQUIRE_GPU=1       no host loop anywhere (see above)
  *     MODGPU_MIN_GPU_BYTES=n     modgpu_cycle_auto_host's size threshold (default 16 MiB, the measured crossover
  *                                against one host thread; 0 = always the GPU)
+ *     MODGPU_HOST_POLICY=name    what modgpu_cycle_auto_host does ABOVE that threshold when a GPU is usable:
+ *                                offload (default) = the kernel -- the host's cores stay free and every GPU adds a link;
+ *                                fastest = per call, the engine the committed crossover table prices as faster for this
+ *                                size and memory kind, the host loop with the threads it would really get
  *     MODGPU_HOST_ISA=name       host-loop body: generic | avx2 | avx512 (default: the best the CPU runs)
  *     MODGPU_HOST_THREADS=n      most host threads one host-loop call may use (default min(cores, 32))
  *     MODGPU_HOST_SPREAD=0       do not give each host-loop worker thread a CPU of its own (leave placement to the scheduler)
@@ -79,7 +83,7 @@ extern "C" {
 #define MODGPU_KEY_PS4 0x90cfc0abu
 
 /* ABI version of this header (bumped on any signature change). */
-#define MODGPU_ABI_VERSION 5
+#define MODGPU_ABI_VERSION 6
 int modgpu_abi_version(void);
 
 /* Number of HIP devices this library addresses (0 if none / runtime unusable).  Normally the
@@ -134,7 +138,10 @@ int modgpu_cycle_scalar_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_
  * which finishes such a buffer before a kernel launch would have returned; larger buffers by modgpu_cycle_host.
  * The reference's Cycle returns void and cannot fail (CEncryptionCycler.cpp:4-14), so when no GPU is visible,
  * or the GPU attempt fails before it has touched host_buf, the host loop finishes the call.  With
- * MODGPU_REQUIRE_GPU=1 there is no second engine: every size runs on the kernel and a GPU error is returned. */
+ * MODGPU_REQUIRE_GPU=1 there is no second engine: every size runs on the kernel and a GPU error is returned.
+ * Above the threshold the default policy is to OFFLOAD: on a host with many cores the threaded host loop is faster than one
+ * GPU's PCIe link for host-resident data (the link, ~50 GB/s, is the bound), but the kernel leaves those cores to the caller
+ * and scales with the number of GPUs; MODGPU_HOST_POLICY=fastest picks the faster engine per call instead. */
 int modgpu_cycle_auto_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, int device);
 
 /* Header framing of CArk::Load (CArk.cpp:328-339) and Decode (Modulate.cpp:475-486):
@@ -227,6 +234,7 @@ typedef struct modgpu_path_stats {
     uint64_t direct_bytes;   /* of gpu_bytes: DMA'd or read straight from the caller's pinned pages */
     uint64_t auto_fallbacks; /* modgpu_cycle_auto_host calls that ended on the host loop because the GPU could not serve them */
     uint64_t auto_small;     /* modgpu_cycle_auto_host calls served by the host loop because n < MODGPU_MIN_GPU_BYTES */
+    uint64_t auto_policy_host; /* modgpu_cycle_auto_host calls of n >= MODGPU_MIN_GPU_BYTES that MODGPU_HOST_POLICY=fastest kept on the host loop */
 } modgpu_path_stats_t;
 /* Process-wide counters since load (or the last reset).  reset != 0 zeroes them after the read. */
 int modgpu_path_stats(modgpu_path_stats_t *out, int reset);
@@ -234,6 +242,12 @@ int modgpu_path_stats(modgpu_path_stats_t *out, int reset);
 int modgpu_gpu_required(void);
 /* modgpu_cycle_auto_host's size threshold as latched from MODGPU_MIN_GPU_BYTES. */
 uint64_t modgpu_min_gpu_bytes(void);
+/* "offload" or "fastest": MODGPU_HOST_POLICY as latched.  Static storage. */
+const char *modgpu_host_policy(void);
+/* What `fastest` would decide for one call over n bytes of pageable (pinned = 0) or page-locked (1) memory on this host:
+ * returns 1 for the host loop, 0 for the kernel, and the two priced durations in microseconds (either pointer may be NULL).
+ * The prices come from the crossover table the library was built with (modulate_amd/csrc/crossover_table.h). */
+int modgpu_host_policy_engine(uint64_t n, int pinned, double *host_us, double *kernel_us);
 /* The host-loop body this process uses: "generic", "avx2" or "avx512".  Static storage. */
 const char *modgpu_host_loop_isa(void);
 

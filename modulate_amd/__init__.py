@@ -14,5 +14,5 @@ from .capi import (  # noqa: F401
     KEY_PS3, KEY_PS4, MAGIC_PS3, MAGIC_PS4, as_int32, EXPORTS, TESTING_EXPORTS, cycle_scalar_host, cycle_auto_host,
     path_stats, gpu_required, last_launch, debug_set_launch, debug_set_pinned_mode, debug_set_staged_mode, kernel_source_hash, host_tunables, debug_inject_failures, PinnedBuffer, host_register, host_unregister,
     DEBUG_EXPORTS, FLAVOURS, testing_flavour, use_testing_flavour, active_flavour, debug_set_queue_ring, debug_set_helpers, queue_stats, testing_hooks, min_gpu_bytes,
-    host_loop_isa, cycle_scalar_host_isa, device_numa_node, numa_probe, host_trace, host_trace_read, host_pool_stats, host_chunking, HOST_TRACE_KINDS,
+    host_loop_isa, cycle_scalar_host_isa, device_numa_node, numa_probe, host_policy, host_policy_engine, host_trace, host_trace_read, host_pool_stats, host_chunking, HOST_TRACE_KINDS,
 )

@@ -55,6 +55,8 @@ EXPORTS = {
     "modgpu_path_stats": (_int, [_vp, _int]),
     "modgpu_gpu_required": (_int, []),
     "modgpu_min_gpu_bytes": (_u64, []),
+    "modgpu_host_policy": (ctypes.c_char_p, []),
+    "modgpu_host_policy_engine": (_int, [_u64, _int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "modgpu_host_loop_isa": (ctypes.c_char_p, []),
     "modgpu_host_alloc_near": (_int, [ctypes.POINTER(_vp), _u64, _int]),
     "modgpu_host_alloc_parts": (_int, [ctypes.POINTER(_vp), ctypes.POINTER(_u64), _int, _int]),
@@ -65,7 +67,7 @@ EXPORTS = {
 class PathStats(ctypes.Structure):
     """modgpu_path_stats_t (include/modgpu.h)."""
     _fields_ = [(k, _u64) for k in ("gpu_calls", "gpu_bytes", "gpu_launches", "scalar_calls", "scalar_bytes",
-                                    "staged_bytes", "direct_bytes", "auto_fallbacks", "auto_small")]
+                                    "staged_bytes", "direct_bytes", "auto_fallbacks", "auto_small", "auto_policy_host")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -293,6 +295,18 @@ def min_gpu_bytes():
     return int(lib().modgpu_min_gpu_bytes())
 
 
+def host_policy():
+    """MODGPU_HOST_POLICY as latched: "offload" or "fastest"."""
+    return lib().modgpu_host_policy().decode()
+
+
+def host_policy_engine(n, pinned=False):
+    """What `fastest` would decide for one call over n bytes: ("host" | "kernel", host_us, kernel_us)."""
+    h, k = ctypes.c_double(0), ctypes.c_double(0)
+    r = lib().modgpu_host_policy_engine(n, 1 if pinned else 0, ctypes.byref(h), ctypes.byref(k))
+    return ("host" if r else "kernel"), h.value, k.value
+
+
 def host_loop_isa():
     return lib().modgpu_host_loop_isa().decode()
 
@@ -323,9 +337,9 @@ def host_tunables():
 
 
 def host_chunking():
-    out = (_u64 * 2)()
+    out = (_u64 * 3)()
     lib().modgpu_host_chunking(out)
-    return {"split": int(out[0]), "chunk_min_bytes": int(out[1])}
+    return {"split": int(out[0]), "chunk_min_bytes": int(out[1]), "ramp_bytes": int(out[2])}
 
 
 def host_trace(enable=True):

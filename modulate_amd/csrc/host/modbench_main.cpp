@@ -216,12 +216,12 @@ int HostTrace()
 {
     if( modgpu_device_count() < 1 ) { std::printf( "no HIP device\n" ); return 1; }
     static const char* kKind[] = { "call_begin", "slots", "posted", "pipe_start", "fill_begin", "fill_end", "launched", "sync_begin", "sync_end", "drain_end", "pipe_end", "call_end" };
-    uint64_t tun[ 4 ], chk[ 2 ];
+    uint64_t tun[ 4 ], chk[ 3 ];
     modgpu_host_tunables( tun );
     modgpu_host_chunking( chk );
     std::printf( "== staged route (pageable caller memory -> pinned slot -> kernel across PCIe on the slot -> back), one call traced per size\n" );
-    std::printf( "   pipelines <= %llu, slot <= %llu MiB, a buffer is cut into ~%llu chunks of >= %llu MiB\n", (unsigned long long)tun[ 0 ], (unsigned long long)( tun[ 1 ] >> 20 ),
-                 (unsigned long long)chk[ 0 ], (unsigned long long)( chk[ 1 ] >> 20 ) );
+    std::printf( "   pipelines <= %llu, slot <= %llu MiB, a buffer is cut into ~%llu chunks of >= %llu MiB, each pipeline's first and last chunk %llu KiB\n", (unsigned long long)tun[ 0 ],
+                 (unsigned long long)( tun[ 1 ] >> 20 ), (unsigned long long)chk[ 0 ], (unsigned long long)( chk[ 1 ] >> 20 ), (unsigned long long)( chk[ 2 ] >> 10 ) );
     for( uint64_t mib : { 16ull, 32ull, 64ull, 128ull, 256ull } )
     {
         const uint64_t n = mib << 20;

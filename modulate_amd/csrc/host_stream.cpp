@@ -94,8 +94,13 @@ const uint64_t kZeroCopyMax = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_
 const int kRing = env_int("MODGPU_HOST_RING", 4, 2, 4);
 //   MODGPU_HOST_SPLIT       a buffer is cut into about this many slots' worth of chunks ...
 //   MODGPU_HOST_CHUNK_MIN_MB  ... of at least this many MiB (and at most MODGPU_HOST_CHUNK_MB)
-const uint64_t kSplit = (uint64_t)env_int("MODGPU_HOST_SPLIT", 16, 2, 256);
-const uint64_t kChunkMin = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_CHUNK_MIN_MB", 4, 1, 256) << 20, kChunk);
+//   MODGPU_HOST_RAMP_KB     each pipeline's FIRST and LAST chunk are this small (0 = all chunks alike): nothing crosses the link
+//                           while the first chunks are being copied in, nor while the last ones are copied out
+// Defaults from profiles/r04_staged_midsize.txt (16 ... 256 MiB, pageable): ~32 chunks of >= 1 MiB is at or near the best row at
+// every size (round 3: ~16 of >= 4 MiB); the timeline there shows why the ramp exists.
+const uint64_t kSplit = (uint64_t)env_int("MODGPU_HOST_SPLIT", 32, 2, 256);
+const uint64_t kChunkMin = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_CHUNK_MIN_MB", 1, 1, 256) << 20, kChunk);
+const uint64_t kRamp = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_RAMP_KB", 512, 0, 1 << 18) << 10, kChunk);
 
 // ---- host-side timeline of the staged / pinned routes (modgpu_host_trace, reporting only) --------------------------------
 std::atomic<bool> g_trace_on{false};
@@ -225,16 +230,36 @@ int drain_slot(const Endpoint &dst, const uint8_t *pinned, uint64_t off, uint64_
     return MODGPU_OK;
 }
 
+struct Piece { uint64_t off, len; };
 struct Job {
     const Endpoint &src, &dst;
-    uint64_t n, chunk;
+    uint64_t n, chunk; // chunk: the largest piece (slot size)
     int32_t key;
     uint64_t stream_off;
     bool slot_kernel = false; // staged chunks are cycled in their pinned slot across PCIe (no DMA, no device slot)
     bool in_dst = false;      // file -> page-locked caller memory: pread lands in the destination itself, which the kernel then
                               // cycles where it lies across PCIe (no slot, no DMA, no copy)
     std::atomic<bool> touched{false};
+    std::vector<Piece> plan; // the stream cut into pieces, in stream order; piece k belongs to pipeline k mod pipes
 };
+
+// Cuts [0, n) into pieces of `chunk` bytes for `pipes` pipelines.  With a ramp the first and the last `pipes` pieces -- every
+// pipeline's first and last -- are only `ramp` bytes: the link carries nothing while the first pieces are copied into their slots
+// and nothing while the last are copied out, and that exposed time shrinks with them (profiles/r04_staged_midsize.txt).
+std::vector<Piece> cut_stream(uint64_t n, uint64_t chunk, int pipes, uint64_t ramp)
+{
+    std::vector<Piece> plan;
+    uint64_t at = 0;
+    const uint64_t edge = (uint64_t)pipes * ramp;
+    const bool ramped = ramp > 0 && ramp < chunk && pipes > 1 && n >= 2 * edge + (uint64_t)pipes * chunk;
+    if (ramped)
+        for (int p = 0; p < pipes; ++p, at += ramp) plan.push_back({at, ramp});
+    const uint64_t middle_end = ramped ? n - edge : n;
+    for (; at < middle_end; at += chunk) plan.push_back({at, std::min<uint64_t>(chunk, middle_end - at)});
+    if (ramped)
+        for (at = middle_end; at < n; at += ramp) plan.push_back({at, std::min<uint64_t>(ramp, n - at)});
+    return plan;
+}
 
 // One pipeline: chunks first, first+stride, ... of the stream through the `ring` slots slots[0..ring).
 // A pinned memory endpoint is DMA'd directly; anything else passes through the slot's pinned buffer.
@@ -242,11 +267,11 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
 {
     const int pipe = (int)first;
     trace(MODGPU_TRACE_PIPE_START, pipe, 0, 0);
-    const uint64_t n_chunks = (j.n + j.chunk - 1) / j.chunk;
+    const uint64_t n_chunks = j.plan.size();
     const bool src_direct = j.src.mem && j.src.pinned, dst_direct = j.dst.mem && j.dst.pinned;
     auto span = [&](uint64_t c, uint64_t *off, uint64_t *len) {
-        *off = c * j.chunk;
-        *len = std::min<uint64_t>(j.chunk, j.n - *off);
+        *off = j.plan[c].off;
+        *len = j.plan[c].len;
     };
     const uint64_t mine = first < n_chunks ? (n_chunks - first + stride - 1) / stride : 0;
     auto step = [&](uint64_t i) -> int {
@@ -481,7 +506,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
                                     : std::min<uint64_t>(kChunk, std::max<uint64_t>(kChunkMin, ((n / kSplit) + 0xFFFFF) & ~0xFFFFFull));
     chunk = std::min<uint64_t>(chunk, kChunk);
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
-    Job job{src, dst, n, chunk, key, stream_off};
+    Job job{src, dst, n, chunk, key, stream_off, false, false, {}, {}};
     // Default routes (profiles/r03_file_routes.txt): pageable memory and files are copied / read into a pinned slot and
     // cycled there across PCIe; a file that ends in page-locked caller memory is read straight into that memory and cycled
     // where it lies; page-locked caller memory that ends in a file is DMA'd.  (Testing flavour, staged mode 1: the DMA
@@ -504,6 +529,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     SlotLease lease(s);
     lease.acquire(pipes * ring, ring);
     pipes = (int)lease.ids.size() / ring;
+    job.plan = cut_stream(n, chunk, pipes, kRamp);
     trace(MODGPU_TRACE_SLOTS, -1, (uint64_t)pipes, chunk);
     rc = staging_reserve(s, lease.ids, chunk, !job.slot_kernel && !job.in_dst, !(src_direct && dst_direct) && !job.in_dst);
     if (rc) return rc;
@@ -572,10 +598,11 @@ void modgpu_host_pool_stats(uint64_t out[5])
     out[4] = (uint64_t)kSlots;
 }
 
-void modgpu_host_chunking(uint64_t out[2])
+void modgpu_host_chunking(uint64_t out[3])
 {
     out[0] = kSplit;
     out[1] = kChunkMin;
+    out[2] = kRamp;
 }
 
 void modgpu_host_tunables(uint64_t out[4])

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/modgpu_testing.h"
+#include "crossover_table.h"
 #include "cycle_kernel.h"
 #include "lcg.h"
 #include "modgpu_internal.h"
@@ -67,6 +68,26 @@ uint64_t min_gpu_bytes()
         char *end = nullptr;
         unsigned long long x = std::strtoull(e, &end, 0);
         return end && end != e ? (uint64_t)x : kMinGpuBytesDefault;
+    }();
+    return v;
+}
+
+// MODGPU_HOST_POLICY (read once): what modgpu_cycle_auto_host -- CEncryptionCycler::Cycle -- does with a buffer of
+// MODGPU_MIN_GPU_BYTES or more when a GPU is usable.
+//   offload (default)  the kernel.  The host's cores stay free for the caller (an unpack walks 100 000 files beside the cipher)
+//                      and every further GPU adds a PCIe link; the headline path is HBM-resident data anyway.
+//   fastest            whichever engine the committed crossover table (crossover_table.h) says finishes THIS call sooner,
+//                      the host loop priced as it really runs: on its threads, as many as this size, the control group's CPU
+//                      quota and the caller's affinity mask give it.  On the node the table was taken on that is the host
+//                      loop at every size (its threads out-run one PCIe link), so `fastest` mostly means "the GPU only when
+//                      the host loop is short of threads".
+// modgpu_path_stats().auto_policy_host counts the calls `fastest` kept on the host.
+enum class HostPolicy { Offload, Fastest };
+HostPolicy host_policy()
+{
+    static const HostPolicy v = [] {
+        const char *e = std::getenv("MODGPU_HOST_POLICY");
+        return e && std::strcmp(e, "fastest") == 0 ? HostPolicy::Fastest : HostPolicy::Offload;
     }();
     return v;
 }
@@ -736,6 +757,12 @@ static int cycle_auto_impl(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t 
         if (rc == MODGPU_OK && n) g_stats.auto_small.fetch_add(1, std::memory_order_relaxed);
         return rc;
     }
+    if (host_policy() == HostPolicy::Fastest && !gpu_required() && logical_count() > 0 &&
+        crossover::host_us(n, modgpu_scalar_isa(), modgpu_scalar_threads_for(n)) < crossover::kernel_us(n, host_range_pinned(host_buf, n))) {
+        int rc = scalar_impl(host_buf, n, key, stream_off);
+        if (rc == MODGPU_OK) g_stats.auto_policy_host.fetch_add(1, std::memory_order_relaxed);
+        return rc;
+    }
     bool touched = false;
     int rc = cycle_host_impl(host_buf, n, key, stream_off, device, &touched);
     if (rc == MODGPU_OK || rc == MODGPU_ERR_INVALID) return rc;
@@ -1087,12 +1114,23 @@ int modgpu_path_stats(modgpu_path_stats_t *out, int reset)
     out->direct_bytes = take(g_stats.direct_bytes);
     out->auto_fallbacks = take(g_stats.auto_fallbacks);
     out->auto_small = take(g_stats.auto_small);
+    out->auto_policy_host = take(g_stats.auto_policy_host);
     return MODGPU_OK;
 }
 
 int modgpu_gpu_required(void) { return gpu_required() ? 1 : 0; }
 
 uint64_t modgpu_min_gpu_bytes(void) { return min_gpu_bytes(); }
+
+const char *modgpu_host_policy(void) { return host_policy() == HostPolicy::Fastest ? "fastest" : "offload"; }
+
+int modgpu_host_policy_engine(uint64_t n, int pinned, double *host_us, double *kernel_us)
+{
+    const double h = crossover::host_us(n, modgpu_scalar_isa(), modgpu_scalar_threads_for(n)), k = crossover::kernel_us(n, pinned != 0);
+    if (host_us) *host_us = h;
+    if (kernel_us) *kernel_us = k;
+    return h < k ? 1 : 0;
+}
 
 const char *modgpu_host_loop_isa(void) { return modgpu_scalar_isa_name(modgpu_scalar_isa()); }
 

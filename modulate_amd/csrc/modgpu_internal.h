@@ -79,7 +79,7 @@ int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_of
 // ---- which engine ran -------------------------------------------------------------------------
 struct Stats {
     std::atomic<uint64_t> gpu_calls{0}, gpu_bytes{0}, gpu_launches{0}, scalar_calls{0}, scalar_bytes{0},
-        staged_bytes{0}, direct_bytes{0}, auto_fallbacks{0}, auto_small{0};
+        staged_bytes{0}, direct_bytes{0}, auto_fallbacks{0}, auto_small{0}, auto_policy_host{0};
 };
 extern Stats g_stats;
 bool gpu_required(); // MODGPU_REQUIRE_GPU=1 at load

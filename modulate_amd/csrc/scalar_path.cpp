@@ -14,7 +14,7 @@
 //   avx2     W = 32: eight ymm registers of four states (vpmuludq), Mersenne fold, packed to 32 bytes
 //   avx512   W = 64: the same with zmm registers (AVX-512 F + BW)
 // Buffers of a few MiB and up are cut into contiguous spans, one per host thread (every span jumps
-// to its own position).
+// to its own position); the threads are parked workers, started on first use (see HostPool below).
 #include "scalar_path.h"
 
 #include <immintrin.h>
@@ -22,8 +22,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -182,31 +187,115 @@ unsigned max_threads()
     return v;
 }
 
-// Worker k of a call runs on the k-th CPU this process may use, skipping the one the calling thread is on
-// (MODGPU_HOST_SPREAD=0: leave placement to the scheduler).  Short-lived threads that the scheduler is left
-// to place can sit on one CPU for their whole life -- measured in a VM: 2 and 4 unpinned workers ran
-// serially (wall = CPU time), 8 spread out -- so each worker is given its own CPU up front.
-struct Spread {
+// CPUs' worth of run time the process's control group may use (cgroup v2 cpu.max, v1 cfs quota / period); 0 = no limit
+// known.  A container given 16 of a host's 256 CPUs sees all 256 in its affinity mask: 32 threads there are throttled by
+// the bandwidth controller in bursts, which is what made round 3's threaded rows erratic (34 GB/s between 56 and 142 at
+// 64 MiB on the MI355X pool's 16-CPU share).  Read once: quotas do not change under a running process as a rule.
+unsigned cgroup_cpu_limit()
+{
+    static const unsigned v = [] {
+        auto read2 = [](const char *path, long long *a, long long *b) {
+            FILE *f = std::fopen(path, "r");
+            if (!f) return 0;
+            char w0[32] = {}, w1[32] = {};
+            const int n = std::fscanf(f, "%31s %31s", w0, w1);
+            std::fclose(f);
+            if (n >= 1) *a = std::strcmp(w0, "max") == 0 ? -1 : std::atoll(w0);
+            if (n >= 2) *b = std::atoll(w1);
+            return n;
+        };
+        long long quota = -1, period = 0, dummy = 0;
+        if (read2("/sys/fs/cgroup/cpu.max", &quota, &period) < 2) { // v1
+            if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &quota, &dummy) < 1 || read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &period, &dummy) < 1) return 0u;
+        }
+        if (quota <= 0 || period <= 0) return 0u;
+        return (unsigned)std::max<long long>(1, (quota + period - 1) / period);
+    }();
+    return v;
+}
+
+// The CPUs the CALLING thread may run on right now (not a snapshot from the first call -- a process may narrow
+// its affinity later, and workers must not be placed outside the mask the caller was given).
+std::vector<int> allowed_cpus()
+{
     std::vector<int> cpus;
-    Spread()
-    {
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) != 0) return cpus;
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+        if (CPU_ISSET(c, &set)) cpus.push_back(c);
+    return cpus;
+}
+bool spread_enabled() // MODGPU_HOST_SPREAD=0: leave the workers' placement to the scheduler
+{
+    static const bool v = [] {
         const char *e = std::getenv("MODGPU_HOST_SPREAD");
-        if (e && std::strcmp(e, "0") == 0) return;
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof set, &set) != 0) return;
-        for (int c = 0; c < CPU_SETSIZE; ++c)
-            if (CPU_ISSET(c, &set)) cpus.push_back(c);
+        return !(e && std::strcmp(e, "0") == 0);
+    }();
+    return v;
+}
+
+// ---- parked workers ---------------------------------------------------------------------------------------------------------
+// One call's spans, drawn by the caller and by parked workers until none is left (round 3 started up to 31 std::threads per
+// call: ~30 us each, a millisecond for a 64 MiB buffer whose arithmetic takes a fifth of that).  Worker k of a call runs on
+// the k-th CPU the CALLER may use, skipping the one the caller is on: threads the scheduler is left to place can sit on one
+// CPU -- measured in a VM: 2 and 4 unpinned workers ran serially -- so a worker binds itself for the length of its span and
+// takes whatever mask the next call hands it.  The caller's own thread is never re-bound.
+struct SpanCall {
+    SpanFn span;
+    uint8_t *buf;
+    uint64_t n, per, count;
+    uint32_t key_res;
+    uint64_t pos;
+    std::vector<int> cpus; // per span index: CPU for a WORKER that draws it (-1 / empty: anywhere in the caller's mask)
+    cpu_set_t caller_mask; // what the caller may run on (a worker left bound to one CPU by an earlier call is widened to it)
+    bool have_mask = false;
+    std::atomic<uint64_t> next{0};
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t finished = 0;
+    void help(bool worker)
+    {
+        for (;;) {
+            const uint64_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= count) return;
+            if (worker && i < cpus.size() && cpus[i] >= 0) {
+                cpu_set_t one;
+                CPU_ZERO(&one);
+                CPU_SET(cpus[i], &one);
+                (void)sched_setaffinity(0, sizeof one, &one); // this worker thread only; best effort
+            } else if (worker && have_mask) {
+                (void)sched_setaffinity(0, sizeof caller_mask, &caller_mask);
+            }
+            const uint64_t off = i * per;
+            span(buf + off, std::min(per, n - off), key_res, pos + off % lcg::PERIOD);
+            std::lock_guard<std::mutex> lock(mu);
+            if (++finished == count) cv.notify_all();
+        }
     }
 };
-void run_span_on(SpanFn span, int cpu, uint8_t *buf, uint64_t n, uint32_t key_res, uint64_t pos)
+struct HostPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<SpanCall>> requests;
+    unsigned workers = 0, parked = 0;
+};
+HostPool *const g_pool = new HostPool; // never destroyed: parked workers wait on it for the life of the process
+std::atomic<unsigned long long> g_pool_threads{0};
+
+void pool_worker()
 {
-    if (cpu >= 0) {
-        cpu_set_t one;
-        CPU_ZERO(&one);
-        CPU_SET(cpu, &one);
-        (void)sched_setaffinity(0, sizeof one, &one); // this worker thread only; best effort
+    std::unique_lock<std::mutex> lock(g_pool->mu);
+    for (;;) {
+        ++g_pool->parked;
+        g_pool->cv.wait(lock, [] { return !g_pool->requests.empty(); });
+        --g_pool->parked;
+        std::shared_ptr<SpanCall> call = std::move(g_pool->requests.front());
+        g_pool->requests.pop_front();
+        lock.unlock();
+        call->help(true);
+        call.reset();
+        lock.lock();
     }
-    span(buf, n, key_res, pos);
 }
 
 } // namespace
@@ -215,37 +304,69 @@ int modgpu_scalar_isa() { return pick_isa(); }
 const char *modgpu_scalar_isa_name(int isa) { return isa >= 0 && isa < MODGPU_ISA_COUNT ? kIsaName[isa] : "?"; }
 bool modgpu_scalar_isa_usable(int isa) { return isa_usable(isa); }
 
+unsigned modgpu_scalar_threads_for(uint64_t n)
+{
+    // a span is worth a thread from ~2 MiB (a few hundred microseconds of work against ~20 us to wake a parked worker)
+    constexpr uint64_t kSpanMin = 2ull << 20;
+    uint64_t t = std::min<uint64_t>(max_threads(), n / kSpanMin);
+    if (const unsigned lim = cgroup_cpu_limit()) t = std::min<uint64_t>(t, lim);
+    return (unsigned)std::max<uint64_t>(t, 1);
+}
+unsigned long long modgpu_scalar_pool_threads() { return g_pool_threads.load(); }
+
 void modgpu_scalar_cycle(uint8_t *buf, uint64_t n, int32_t key, uint64_t stream_off, int isa)
 {
     const uint32_t key_res = lcg::key_residue(key);
     if (n == 0 || key_res == 0) return; // residue 0 sticks at m: keystream all zero (identity)
     const SpanFn span = kSpan[isa >= 0 && isa < MODGPU_ISA_COUNT && isa_usable(isa) ? isa : pick_isa()];
     const uint64_t pos = stream_off % lcg::PERIOD;
-    // a span is worth a thread from ~2 MiB (a few hundred microseconds of work against ~30 us to start one)
-    constexpr uint64_t kSpanMin = 2ull << 20;
-    uint64_t threads = std::min<uint64_t>(max_threads(), n / kSpanMin);
+    uint64_t threads = modgpu_scalar_threads_for(n);
+    std::vector<int> cpus;
+    if (threads > 1) {
+        cpus = allowed_cpus();
+        if (!cpus.empty()) threads = std::min<uint64_t>(threads, cpus.size());
+    }
     if (threads <= 1) {
         span(buf, n, key_res, pos);
         return;
     }
-    const uint64_t per = ((n + threads - 1) / threads + 63) & ~63ull;
-    static const Spread spread;
-    const int here = sched_getcpu();
-    static std::atomic<size_t> rotate{0}; // concurrent calls start their workers on different CPUs instead of all on the first ones
-    size_t next_cpu = rotate.fetch_add((size_t)threads, std::memory_order_relaxed);
-    auto worker_cpu = [&]() -> int { // the next allowed CPU that is not the caller's; -1: leave it to the scheduler
-        if (spread.cpus.size() < threads) return -1;
-        if (spread.cpus[next_cpu % spread.cpus.size()] == here) ++next_cpu;
-        return spread.cpus[next_cpu++ % spread.cpus.size()];
-    };
-    std::vector<std::thread> pool;
-    try {
-        for (uint64_t off = per; off < n; off += per)
-            pool.emplace_back(run_span_on, span, worker_cpu(), buf + off, std::min(per, n - off), key_res, pos + off % lcg::PERIOD);
-    } catch (...) { // thread limit reached: finish what was not handed out on this thread
-        uint64_t done = per * (pool.size() + 1);
-        if (done < n) span(buf + done, n - done, key_res, pos + done % lcg::PERIOD);
+    auto call = std::make_shared<SpanCall>();
+    call->span = span;
+    call->buf = buf;
+    call->n = n;
+    call->per = ((n + threads - 1) / threads + 63) & ~63ull;
+    call->count = (n + call->per - 1) / call->per;
+    call->key_res = key_res;
+    call->pos = pos;
+    call->have_mask = sched_getaffinity(0, sizeof call->caller_mask, &call->caller_mask) == 0;
+    if (spread_enabled() && cpus.size() >= call->count) {
+        // span i (when a worker draws it) -> the next allowed CPU that is not the caller's; concurrent calls start at different CPUs
+        static std::atomic<size_t> rotate{0};
+        size_t at = rotate.fetch_add((size_t)call->count, std::memory_order_relaxed);
+        const int here = sched_getcpu();
+        call->cpus.resize((size_t)call->count, -1);
+        for (uint64_t i = 0; i < call->count; ++i) {
+            if (cpus[at % cpus.size()] == here) ++at;
+            call->cpus[(size_t)i] = cpus[at++ % cpus.size()];
+        }
     }
-    span(buf, std::min(per, n), key_res, pos);
-    for (auto &t : pool) t.join();
+    {
+        std::lock_guard<std::mutex> lock(g_pool->mu);
+        const unsigned extra = (unsigned)call->count - 1;
+        for (unsigned k = 0; k < extra; ++k) g_pool->requests.push_back(call);
+        const int short_of = (int)g_pool->requests.size() - (int)g_pool->parked;
+        for (int k = 0; k < short_of && g_pool->workers + 1 < max_threads(); ++k) {
+            try {
+                std::thread(pool_worker).detach();
+                ++g_pool->workers;
+                g_pool_threads.fetch_add(1, std::memory_order_relaxed);
+            } catch (...) { // thread limit: the caller simply does more of the spans itself
+                break;
+            }
+        }
+    }
+    g_pool->cv.notify_all();
+    call->help(false);
+    std::unique_lock<std::mutex> lock(call->mu);
+    call->cv.wait(lock, [&] { return call->finished == call->count; });
 }

@@ -10,3 +10,7 @@ void modgpu_scalar_cycle(uint8_t *buf, uint64_t n, int32_t key, uint64_t stream_
 int modgpu_scalar_isa();                       // the automatic choice
 const char *modgpu_scalar_isa_name(int isa);   // "generic" / "avx2" / "avx512"
 bool modgpu_scalar_isa_usable(int isa);
+// threads (the caller included) a call over n bytes spreads its spans over: MODGPU_HOST_THREADS (default min(cores, 32)),
+// one per 2 MiB, never more than the control group's CPU quota or the caller's affinity mask allow
+unsigned modgpu_scalar_threads_for(uint64_t n);
+unsigned long long modgpu_scalar_pool_threads(); // worker threads started so far (they park between calls)

@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(modgpu):
     assert modgpu.active_flavour() == "shipped" and not modgpu.testing_hooks()
     for name in list(modgpu.EXPORTS) + list(modgpu.TESTING_EXPORTS):
         assert getattr(L, name) is not None
-    assert L.modgpu_abi_version() == 5
+    assert L.modgpu_abi_version() == 6
 
     def exported(path):
         out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
@@ -236,6 +236,46 @@ def test_min_gpu_bytes_knob_is_latched_at_load(setting, want):
     env.update(MODGPU_MIN_GPU_BYTES=setting, PYTHONPATH=ROOT, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT)
     assert r.returncode == 0 and "KNOB_OK" in r.stdout and f"MIN {want}\n" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("setting,want", [(None, "offload"), ("offload", "offload"), ("fastest", "fastest"), ("nonsense", "offload")])
+def test_host_policy_is_latched_at_load_and_priced_from_the_table(setting, want):
+    """what modgpu_cycle_auto_host does above MODGPU_MIN_GPU_BYTES is a stated, switchable policy.
+    MODGPU_HOST_POLICY is read once; `fastest` decides per call from the committed crossover table
+    (modulate_amd/csrc/crossover_table.h), pricing the host loop with the threads it would really get -- so with ONE thread
+    allowed the kernel wins from the table's crossover up, with many threads the host loop wins on this node class, and
+    page-locked memory (no staging copies) moves the kernel's price down."""
+    code = ("import json, modulate_amd as M\n"
+            "r = {'policy': M.host_policy(), 'min': M.min_gpu_bytes()}\n"
+            "for mib in (4, 16, 32, 64, 256, 1024):\n"
+            "    r[str(mib)] = [M.host_policy_engine(mib << 20, p) for p in (False, True)]\n"
+            "print('R', json.dumps(r))\n")
+    import json
+    out = {}
+    for threads in ("1", "32"):
+        env = {k: v for k, v in os.environ.items() if k not in ("MODGPU_HOST_POLICY", "MODGPU_HOST_THREADS")}
+        env.update(PYTHONPATH=ROOT, MODGPU_HOST_THREADS=threads, MODGPU_HOST_ISA="avx512")
+        if setting is not None:
+            env["MODGPU_HOST_POLICY"] = setting
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[threads] = json.loads(r.stdout.split("R ", 1)[1])
+        assert out[threads]["policy"] == want
+    one, many = out["1"], out["32"]
+    if "avx512" != __import__("modulate_amd").host_loop_isa():
+        return  # (the prices below are the AVX-512 body's; a CPU without it is priced by its own body)
+    # one host thread (17 GB/s): behind the staged kernel route from a few tens of MiB up, ahead at 4 MiB (the two meet near 16 MiB)
+    assert one["4"][0][0] == "host"
+    assert one["64"][0][0] == "kernel" and one["1024"][0][0] == "kernel"
+    assert one["16"][1][0] == "kernel"  # page-locked memory: 50 GB/s across the link beats one thread at every size of the table
+    # the threads this machine allows: priced at threads x 17.2 x 0.75, so the table's answer depends on the machine's CPU count
+    import multiprocessing
+    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else multiprocessing.cpu_count()
+    if cpus >= 8:
+        assert many["256"][0][0] == "host" and many["1024"][0][0] == "host"  # >= 8 threads: > 100 GB/s against a 50 GB/s link
+    for mib in ("16", "64", "1024"):
+        assert many[mib][0][1] <= one[mib][0][1]  # more threads never price the host loop slower
+        assert one[mib][1][2] <= one[mib][0][2]   # pinned memory never prices the kernel slower than pageable
 
 
 @needs_host_loop

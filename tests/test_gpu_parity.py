@@ -1106,3 +1106,36 @@ def test_the_tuners_validity_check_sees_a_wrong_keystream():
     assert "** FAILS **" in lines["modgpu_cycle_queue_kernel<4, 1024>"] and "** FAILS **" in lines["modgpu_cycle_kernel<8, 1024, 2, true>"], bad.stdout
     assert lines["modgpu_cycle_kernel<1, 256, 1, false>"].rstrip().endswith("ok")  # the small shape does not use the block
 
+
+def test_host_policy_offload_and_fastest_on_a_machine_with_a_gpu(oracle):
+    """VERDICT r3 #4.  Above MODGPU_MIN_GPU_BYTES modgpu_cycle_auto_host (what CEncryptionCycler::Cycle binds to) OFFLOADS by
+    default: a 48 MiB pageable buffer runs on the kernel (gpu_calls moves).  Under MODGPU_HOST_POLICY=fastest the same call goes to
+    whichever engine the committed crossover table prices as faster with the host threads this box really grants: the
+    decision function and the counters must agree, and the bytes are the oracle's either way.  (Child processes: the policy,
+    like MODGPU_REQUIRE_GPU, is latched at load; the host loop must be allowed for `fastest` to have a choice.)"""
+    import json
+    code = ("import json, numpy as np, modulate_amd as M\n"
+            "from oracle import oracle as O\n"
+            "n = 48 << 20\n"
+            "pt = O.splitmix_bytes(n, 4)\n"
+            "want = O.cycle(pt.copy(), M.KEY_PS4)\n"
+            "b = M.path_stats()\n"
+            "got = M.cycle_auto_host(pt.copy(), M.KEY_PS4)\n"
+            "a = M.path_stats()\n"
+            "print('R', json.dumps({'ok': bool(np.array_equal(got, want)), 'policy': M.host_policy(), 'engine': M.host_policy_engine(n, False)[0],\n"
+            "      'gpu_calls': a['gpu_calls'] - b['gpu_calls'], 'scalar_calls': a['scalar_calls'] - b['scalar_calls'],\n"
+            "      'policy_host': a['auto_policy_host'] - b['auto_policy_host'], 'fallbacks': a['auto_fallbacks'] - b['auto_fallbacks']}))\n")
+    res = {}
+    for policy in ("offload", "fastest"):
+        env = dict(os.environ, PYTHONPATH=ROOT, MODGPU_REQUIRE_GPU="0", MODGPU_HOST_POLICY=policy)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res[policy] = json.loads(r.stdout.split("R ", 1)[1])
+        assert res[policy]["ok"] and res[policy]["policy"] == policy and res[policy]["fallbacks"] == 0
+    assert res["offload"]["gpu_calls"] == 1 and res["offload"]["scalar_calls"] == 0 and res["offload"]["policy_host"] == 0
+    f = res["fastest"]
+    if f["engine"] == "host":
+        assert f["policy_host"] == 1 and f["scalar_calls"] == 1 and f["gpu_calls"] == 0
+    else:
+        assert f["policy_host"] == 0 and f["gpu_calls"] == 1 and f["scalar_calls"] == 0
+

@@ -23,10 +23,13 @@ for mib in (16, 32, 64, 128, 256):
     out.append("%%6.2f ms %%5.1f GB/s" %% (best * 1e3, n / best / 1e9))
 print(" | ".join(out))
 """
-print("%-44s | " % "setting" + " | ".join("%3d MiB            " % m for m in (16, 32, 64, 128, 256)))
-# (split, smallest chunk MiB, pipelines): a buffer is cut into ~split chunks of at least that size (and at most MODGPU_HOST_CHUNK_MB = 8)
-for split, cmin, pipes in ((16, 4, 8), (16, 2, 8), (16, 1, 8), (32, 2, 8), (32, 1, 8), (64, 1, 8), (32, 2, 16), (32, 1, 16), (64, 1, 16), (16, 4, 4), (32, 2, 4)):
-    env = dict(os.environ, MODGPU_REQUIRE_GPU="1", MODGPU_HOST_PIPES=str(pipes), MODGPU_HOST_SPLIT=str(split), MODGPU_HOST_CHUNK_MIN_MB=str(cmin))
+print("%-58s | " % "setting" + " | ".join("%3d MiB            " % m for m in (16, 32, 64, 128, 256)))
+# (split, smallest chunk MiB, pipelines, ramp KiB): a buffer is cut into ~split chunks of at least that size (and at most MODGPU_HOST_CHUNK_MB = 8);
+# each pipeline's first and last chunk are `ramp` KiB (0: all alike)
+DEFAULT = (32, 1, 8, 512)
+for split, cmin, pipes, ramp in (DEFAULT, (32, 1, 8, 0), (32, 1, 8, 256), (32, 1, 8, 1024), (16, 4, 8, 0), (16, 4, 8, 512), (32, 2, 8, 512), (64, 1, 8, 512), (64, 1, 8, 256),
+                                 (32, 1, 16, 512), (32, 1, 12, 512), (32, 1, 6, 512)):
+    env = dict(os.environ, MODGPU_REQUIRE_GPU="1", MODGPU_HOST_PIPES=str(pipes), MODGPU_HOST_SPLIT=str(split), MODGPU_HOST_CHUNK_MIN_MB=str(cmin), MODGPU_HOST_RAMP_KB=str(ramp))
     r = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, env=env, timeout=600)
-    print("%-44s | %s" % ("~%d chunks of >= %d MiB, %2d pipelines%s" % (split, cmin, pipes, "  (default)" if (split, cmin, pipes) == (16, 4, 8) else ""),
-                          r.stdout.strip() or r.stderr[-300:]), flush=True)
+    note = "  (default)" if (split, cmin, pipes, ramp) == DEFAULT else "  (round 3)" if (split, cmin, pipes, ramp) == (16, 4, 8, 0) else ""
+    print("%-58s | %s" % ("~%d chunks of >= %d MiB, %2d pipelines, ramp %4d KiB%s" % (split, cmin, pipes, ramp, note), r.stdout.strip() or r.stderr[-300:]), flush=True)
