@@ -49,8 +49,9 @@ int modgpu_last_launch(modgpu_launch_info_t *out);
 void modgpu_host_tunables(uint64_t out[4]);
 /* ... and the three that shape the chunks of a staged buffer: out[0] = MODGPU_HOST_SPLIT (a buffer is cut into about this many
  * chunks), out[1] = smallest such chunk in bytes (MODGPU_HOST_CHUNK_MIN_MB, never above the largest slot), out[2] = size of each
- * pipeline's first and last chunk in bytes (MODGPU_HOST_RAMP_KB; 0 = no ramp). */
-void modgpu_host_chunking(uint64_t out[3]);
+ * pipeline's first and last chunk in bytes (MODGPU_HOST_RAMP_KB; 0 = no ramp), out[3] = streams a call's kernels across PCIe are
+ * queued on in launch order (MODGPU_HOST_LANES; 0 = one stream per slot). */
+void modgpu_host_chunking(uint64_t out[4]);
 
 /* Host-side timeline of the host-buffer / file routes: while enabled, every call of modgpu_cycle_host and
  * the file entry points records what it did and when (CLOCK_MONOTONIC ns): the call's begin and end, the slots it got

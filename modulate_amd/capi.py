@@ -337,9 +337,9 @@ def host_tunables():
 
 
 def host_chunking():
-    out = (_u64 * 3)()
+    out = (_u64 * 4)()
     lib().modgpu_host_chunking(out)
-    return {"split": int(out[0]), "chunk_min_bytes": int(out[1]), "ramp_bytes": int(out[2])}
+    return {"split": int(out[0]), "chunk_min_bytes": int(out[1]), "ramp_bytes": int(out[2]), "lanes": int(out[3])}
 
 
 def host_trace(enable=True):

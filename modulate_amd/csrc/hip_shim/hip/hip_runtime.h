@@ -54,6 +54,8 @@ hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t s);
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t s);
 hipError_t hipEventCreate(hipEvent_t *e);
+constexpr unsigned hipEventDisableTiming = 2;
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);

@@ -145,6 +145,7 @@ hipError_t hipMemset(void *p, int v, size_t n) { hipMemsetAsync(p, v, n, nullptr
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t s) { resolve(s)->push(run_copy, new CopyJob{dst, src, n, 0, false}); return hipSuccess; }
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k) { hipMemcpyAsync(dst, src, n, k, nullptr); return hipStreamSynchronize(nullptr); }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = new ShimEvent; return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
 {

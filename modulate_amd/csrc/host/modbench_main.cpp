@@ -3,7 +3,7 @@
 //   modbench [part_bytes=4294967296] [steps=20] [warmup=3] [device=0]
 //       bench.py's measurement: a step is one encrypt pass + one decrypt pass over an HBM-resident part; prints payload
 //       GB/s and the HBM read+write GB/s of the mean launch (HIP events on the launch stream, inside the library).
-//   modbench --parts N [--devices d0,d1,...] [--part-bytes B] [--steps S] [--warmup W]
+//   modbench --parts N [--devices d0,d1,... | a..b] [--part-bytes B] [--steps S] [--warmup W]
 //       ONE process driving N resident parts, part i on devices[i mod len] (BASELINE config 3's shape), through
 //       modgpu_cycle_parts_device: aggregate GB/s of the whole job by the wall clock, pass 1 checked against the
 //       library's own closed form on windows, an even number of passes against the input.
@@ -122,6 +122,30 @@ int Parts( int nParts, std::vector< int > devices, uint64_t n, int steps, int wa
         const uint64_t off = n > win.size() ? n - win.size() : 0;
         for( uint64_t j = 0; j < std::min< uint64_t >( win.size(), n ); ++j ) ok = ok && win[ j ] == tile[ ( off + j ) % tile.size() ];
     }
+    // Each device's parts alone, and ONE part alone (the N = 1 line): what the aggregate is to be held against.  Fewer steps:
+    // these are reference points, the aggregate above is the measurement.
+    std::vector< int > distinct;
+    for( int d : where ) if( std::find( distinct.begin(), distinct.end(), d ) == distinct.end() ) distinct.push_back( d );
+    const int refSteps = std::max( 2, steps / 4 );
+    auto timeSubset = [ & ]( const std::vector< int >& idx ) -> double {
+        std::vector< void* > p; std::vector< uint64_t > z; std::vector< int > w;
+        for( int i : idx ) { p.push_back( parts[ (size_t)i ] ); z.push_back( n ); w.push_back( where[ (size_t)i ] ); }
+        auto go = [ & ]() { return modgpu_cycle_parts_device( p.data(), z.data(), w.data(), (int)p.size(), kKey ); };
+        if( go() != MODGPU_OK || go() != MODGPU_OK ) return -1.0;
+        const double t = Now();
+        for( int s2 = 0; s2 < refSteps; ++s2 ) { if( go() != MODGPU_OK || go() != MODGPU_OK ) return -1.0; }
+        return 2.0 * refSteps * idx.size() * (double)n / ( Now() - t ) / 1e9;
+    };
+    std::string perDevice;
+    for( size_t k = 0; k < distinct.size(); ++k )
+    {
+        std::vector< int > idx;
+        for( int i = 0; i < nParts; ++i ) if( where[ (size_t)i ] == distinct[ k ] ) idx.push_back( i );
+        char b[ 64 ];
+        std::snprintf( b, sizeof b, "%s{\"device\": %d, \"parts\": %zu, \"GBps\": %.1f}", k ? ", " : "", distinct[ k ], idx.size(), timeSubset( idx ) );
+        perDevice += b;
+    }
+    const double n1 = timeSubset( { 0 } );
     std::string devs;
     for( size_t i = 0; i < devices.size(); ++i ) devs += ( i ? "," : "" ) + std::to_string( devices[ i ] );
     std::printf( "{\"mode\": \"parts\", \"parts\": %d, \"devices\": [%s], \"logical_devices_visible\": %d, \"part_bytes\": %llu, \"steps\": %d, "
@@ -130,6 +154,16 @@ int Parts( int nParts, std::vector< int > devices, uint64_t n, int steps, int wa
                  nParts, devs.c_str(), avail, (unsigned long long)n, steps, 2.0 * steps * nParts * (double)n / dt / 1e9,
                  4.0 * steps * nParts * (double)n / dt / 1e9, dt / ( 2.0 * steps ) * 1e3,
                  (double)( st1.gpu_launches - st0.gpu_launches ) / ( 2.0 * steps ), last.kernel ? last.kernel : "?", ok ? "true" : "false" );
+    // The same job in the bench contract's shape (bench.py's line at --gpus N comes from N processes; this is ONE process
+    // driving N devices), with what bench.py never reports itself: each device's own rate and the efficiency against N x the
+    // one-part line.  On aliased devices (MODGPU_DEVICE_ALIAS) every "device" is the same GPU and the efficiency says so.
+    const double agg = 2.0 * steps * nParts * (double)n / dt / 1e9;
+    std::printf( "{\"metric\": \"GB/s encrypt+decrypt over synthetic .ark parts; %% HBM peak at 1/2/4/8 GPU\", \"value\": %.2f, \"unit\": \"GB/s\", \"n_gpus\": %zu, "
+                 "\"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.4f, \"higher_is_better\": true, \"scaling\": \"weak\", \"vs_baseline\": null, \"dtype\": \"u8\", "
+                 "\"data\": \"synthetic\", \"config\": {\"workload\": \"config 3 in ONE process: %d x %llu B resident parts over %zu device(s), modgpu_cycle_parts_device\", "
+                 "\"parallelism\": \"parts%zu\"}, \"per_device\": [%s], \"n1_value\": %.2f, \"efficiency_vs_n_times_n1\": %.4f, \"bit_exact_windows\": %s}\n",
+                 agg, distinct.size(), steps, warmup, dt / steps * 1e3, nParts, (unsigned long long)n, distinct.size(), distinct.size(), perDevice.c_str(), n1,
+                 n1 > 0 ? agg / ( n1 * (double)distinct.size() ) : 0.0, ok ? "true" : "false" );
     for( int i = 0; i < nParts; ++i ) TRY( modgpu_free( parts[ i ], where[ i ] ) );
     return ok ? 0 : 2;
 }
@@ -216,12 +250,12 @@ int HostTrace()
 {
     if( modgpu_device_count() < 1 ) { std::printf( "no HIP device\n" ); return 1; }
     static const char* kKind[] = { "call_begin", "slots", "posted", "pipe_start", "fill_begin", "fill_end", "launched", "sync_begin", "sync_end", "drain_end", "pipe_end", "call_end" };
-    uint64_t tun[ 4 ], chk[ 3 ];
+    uint64_t tun[ 4 ], chk[ 4 ];
     modgpu_host_tunables( tun );
     modgpu_host_chunking( chk );
     std::printf( "== staged route (pageable caller memory -> pinned slot -> kernel across PCIe on the slot -> back), one call traced per size\n" );
-    std::printf( "   pipelines <= %llu, slot <= %llu MiB, a buffer is cut into ~%llu chunks of >= %llu MiB, each pipeline's first and last chunk %llu KiB\n", (unsigned long long)tun[ 0 ],
-                 (unsigned long long)( tun[ 1 ] >> 20 ), (unsigned long long)chk[ 0 ], (unsigned long long)( chk[ 1 ] >> 20 ), (unsigned long long)( chk[ 2 ] >> 10 ) );
+    std::printf( "   pipelines <= %llu, slot <= %llu MiB, a buffer is cut into ~%llu chunks of >= %llu MiB, each pipeline's first and last chunk %llu KiB, kernels queued on %llu lane(s)\n", (unsigned long long)tun[ 0 ],
+                 (unsigned long long)( tun[ 1 ] >> 20 ), (unsigned long long)chk[ 0 ], (unsigned long long)( chk[ 1 ] >> 20 ), (unsigned long long)( chk[ 2 ] >> 10 ), (unsigned long long)chk[ 3 ] );
     for( uint64_t mib : { 16ull, 32ull, 64ull, 128ull, 256ull } )
     {
         const uint64_t n = mib << 20;
@@ -487,9 +521,13 @@ int Numa( uint64_t n )
 std::vector< int > IntList( const char* s )
 {
     std::vector< int > v;
-    for( const char* p = s; *p; )
+    for( const char* p = s; *p; ) // "0,2,5" or ranges "0..7" (also mixed: "0..3,6")
     {
-        v.push_back( std::atoi( p ) );
+        const int a = std::atoi( p );
+        int b = a;
+        while( *p && *p != ',' && *p != '.' ) ++p;
+        if( p[ 0 ] == '.' && p[ 1 ] == '.' ) { b = std::atoi( p + 2 ); while( *p && *p != ',' ) ++p; }
+        for( int d = a; d <= b && d - a < 64; ++d ) v.push_back( d );
         while( *p && *p != ',' ) ++p;
         if( *p == ',' ) ++p;
     }

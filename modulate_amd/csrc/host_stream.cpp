@@ -101,6 +101,13 @@ const int kRing = env_int("MODGPU_HOST_RING", 4, 2, 4);
 const uint64_t kSplit = (uint64_t)env_int("MODGPU_HOST_SPLIT", 32, 2, 256);
 const uint64_t kChunkMin = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_CHUNK_MIN_MB", 1, 1, 256) << 20, kChunk);
 const uint64_t kRamp = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_RAMP_KB", 512, 0, 1 << 18) << 10, kChunk);
+//   MODGPU_HOST_LANES       streams a call's kernels-across-PCIe are queued on, in launch order, round robin (0 = every slot its
+//                           own stream, the round-3 form).  With a stream per slot the GPU runs all 16 chunk kernels of a call at
+//                           once, each on a sixteenth of the link, and they all finish late together -- the first chunk's bytes
+//                           come back when the last chunk's do, and nothing can be copied out meanwhile
+//                           (profiles/r04_staged_midsize.txt: a 512 KiB kernel launched at 20 us returned at 510 us).  Two lanes
+//                           keep the link full across the gap between kernels and still finish chunks in the order they came.
+const int kLanes = env_int("MODGPU_HOST_LANES", 2, 0, 8);
 
 // ---- host-side timeline of the staged / pinned routes (modgpu_host_trace, reporting only) --------------------------------
 std::atomic<bool> g_trace_on{false};
@@ -128,6 +135,7 @@ struct Staging {
     hipStream_t stream[kSlots] = {};
     uint64_t pinned_cap[kSlots] = {};
     uint64_t dev_cap[kSlots] = {};
+    hipEvent_t event[kSlots] = {};              // "the kernel queued for this slot has finished" when it ran on a shared lane
     bool busy[kSlots] = {};                     // under mu
     std::deque<std::shared_ptr<Call>> requests; // under mu: one entry per pipeline a call would like a worker for
     int workers = 0, parked = 0;                // under mu
@@ -180,6 +188,7 @@ int staging_reserve(Staging &s, const std::vector<int> &ids, uint64_t need, bool
     need = std::min<uint64_t>(std::max<uint64_t>(need, 1ull << 20), kChunk);
     for (int i : ids) {
         if (!s.stream[i]) HIP_TRY(hipStreamCreateWithFlags(&s.stream[i], hipStreamNonBlocking));
+        if (!s.event[i]) HIP_TRY(hipEventCreateWithFlags(&s.event[i], hipEventDisableTiming));
         if (want_pinned && s.pinned_cap[i] < need) {
             if (s.pinned[i]) HIP_TRY(hipHostFree(s.pinned[i]));
             s.pinned[i] = nullptr;
@@ -241,6 +250,8 @@ struct Job {
                               // cycles where it lies across PCIe (no slot, no DMA, no copy)
     std::atomic<bool> touched{false};
     std::vector<Piece> plan; // the stream cut into pieces, in stream order; piece k belongs to pipeline k mod pipes
+    std::vector<hipStream_t> lanes; // kernels across PCIe are queued on these in launch order (empty: each on its slot's stream)
+    std::atomic<uint64_t> launched{0};
 };
 
 // Cuts [0, n) into pieces of `chunk` bytes for `pipes` pipelines.  With a ramp the first and the last `pipes` pieces -- every
@@ -274,6 +285,14 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
         *len = j.plan[c].len;
     };
     const uint64_t mine = first < n_chunks ? (n_chunks - first + stride - 1) / stride : 0;
+    // kernels that work across PCIe (on the slot, or on the caller's page-locked destination) share the call's lanes
+    const bool on_lanes = !j.lanes.empty() && (j.slot_kernel || j.in_dst);
+    auto launch_across_pcie = [&](void *mapped, uint64_t len, uint64_t off, int slot) -> int {
+        hipStream_t st = on_lanes ? j.lanes[j.launched.fetch_add(1, std::memory_order_relaxed) % j.lanes.size()] : s.stream[slot];
+        int rc = cycle_device_impl(mapped, len, j.key, j.stream_off + off, st, /*over_pcie=*/true);
+        if (rc == MODGPU_OK && on_lanes) HIP_TRY(hipEventRecord(s.event[slot], st));
+        return rc;
+    };
     auto step = [&](uint64_t i) -> int {
         const int slot = slots[i % (uint64_t)ring];
         if (i >= (uint64_t)ring) { // retire the chunk that used this slot `ring` trips ago
@@ -281,7 +300,8 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
             const uint64_t c = first + (i - ring) * stride;
             span(c, &off, &len);
             trace(MODGPU_TRACE_SYNC_BEGIN, pipe, c, len);
-            HIP_TRY(hipStreamSynchronize(s.stream[slot]));
+            if (on_lanes) HIP_TRY(hipEventSynchronize(s.event[slot]));
+            else HIP_TRY(hipStreamSynchronize(s.stream[slot]));
             trace(MODGPU_TRACE_SYNC_END, pipe, c, len);
             if (!dst_direct && !j.in_dst) {
                 j.touched.store(true, std::memory_order_relaxed);
@@ -302,7 +322,7 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
                 trace(MODGPU_TRACE_FILL_END, pipe, c, len);
                 void *mapped = nullptr;
                 HIP_TRY(hipHostGetDevicePointer(&mapped, j.dst.mem + off, 0));
-                rc = cycle_device_impl(mapped, len, j.key, j.stream_off + off, s.stream[slot], /*over_pcie=*/true);
+                rc = launch_across_pcie(mapped, len, off, slot);
                 trace(MODGPU_TRACE_LAUNCHED, pipe, c, len);
                 return rc;
             }
@@ -312,7 +332,7 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
                 trace(MODGPU_TRACE_FILL_END, pipe, c, len);
                 void *mapped = nullptr;
                 HIP_TRY(hipHostGetDevicePointer(&mapped, s.pinned[slot], 0));
-                rc = cycle_device_impl(mapped, len, j.key, j.stream_off + off, s.stream[slot], /*over_pcie=*/true);
+                rc = launch_across_pcie(mapped, len, off, slot);
                 trace(MODGPU_TRACE_LAUNCHED, pipe, c, len);
                 return rc;
             }
@@ -341,6 +361,7 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
     if (rc != MODGPU_OK) { // nothing of this call may still be running against the caller's memory once we return
         const std::string keep = t_err;
         for (int k = 0; k < ring; ++k) (void)hipStreamSynchronize(s.stream[slots[k]]);
+        for (hipStream_t st : j.lanes) (void)hipStreamSynchronize(st);
         (void)hipGetLastError();
         t_err = keep;
     }
@@ -506,7 +527,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
                                     : std::min<uint64_t>(kChunk, std::max<uint64_t>(kChunkMin, ((n / kSplit) + 0xFFFFF) & ~0xFFFFFull));
     chunk = std::min<uint64_t>(chunk, kChunk);
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
-    Job job{src, dst, n, chunk, key, stream_off, false, false, {}, {}};
+    Job job{src, dst, n, chunk, key, stream_off, false, false, {}, {}, {}, {}};
     // Default routes (profiles/r03_file_routes.txt): pageable memory and files are copied / read into a pinned slot and
     // cycled there across PCIe; a file that ends in page-locked caller memory is read straight into that memory and cycled
     // where it lies; page-locked caller memory that ends in a file is DMA'd.  (Testing flavour, staged mode 1: the DMA
@@ -530,9 +551,11 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     lease.acquire(pipes * ring, ring);
     pipes = (int)lease.ids.size() / ring;
     job.plan = cut_stream(n, chunk, pipes, kRamp);
+    for (int k = 0; k < kLanes && k < (int)lease.ids.size(); ++k) job.lanes.push_back(nullptr); // (streams exist after staging_reserve)
     trace(MODGPU_TRACE_SLOTS, -1, (uint64_t)pipes, chunk);
     rc = staging_reserve(s, lease.ids, chunk, !job.slot_kernel && !job.in_dst, !(src_direct && dst_direct) && !job.in_dst);
     if (rc) return rc;
+    for (size_t k = 0; k < job.lanes.size(); ++k) job.lanes[k] = s.stream[lease.ids[k]];
 
     if (pipes <= 1) {
         rc = run_pipe(s, lease.ids.data(), ring, job, 0, 1);
@@ -598,11 +621,12 @@ void modgpu_host_pool_stats(uint64_t out[5])
     out[4] = (uint64_t)kSlots;
 }
 
-void modgpu_host_chunking(uint64_t out[3])
+void modgpu_host_chunking(uint64_t out[4])
 {
     out[0] = kSplit;
     out[1] = kChunkMin;
     out[2] = kRamp;
+    out[3] = (uint64_t)kLanes;
 }
 
 void modgpu_host_tunables(uint64_t out[4])

@@ -1139,3 +1139,25 @@ def test_host_policy_offload_and_fastest_on_a_machine_with_a_gpu(oracle):
     else:
         assert f["policy_host"] == 0 and f["gpu_calls"] == 1 and f["scalar_calls"] == 0
 
+
+def test_one_process_n_parts_line_in_the_bench_contracts_shape():
+    """bin/modbench --parts N --devices a..b drives N resident parts over N devices from ONE process through
+    modgpu_cycle_parts_device (now on a private non-blocking stream per device, not the legacy NULL stream) and prints, beside
+    its own record, the job in the bench contract's shape with each device's own rate, the one-part line and the efficiency
+    against N x that line.  Here four aliased devices on this box's one GPU: the shape and the checks are what is tested --
+    the efficiency of four aliases of ONE GPU is about 1/4 and says so."""
+    import json
+    env = dict(os.environ, MODGPU_DEVICE_ALIAS="4")
+    r = subprocess.run([os.path.join(ROOT, "modulate_amd", "bin", "modbench"), "--parts", "4", "--devices", "0..3", "--part-bytes", str((300 << 20) + 5),
+                        "--steps", "4", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 2 and lines[0]["mode"] == "parts" and lines[0]["bit_exact_windows"] is True
+    c = lines[1]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in c, k
+    assert c["n_gpus"] == 4 and c["scaling"] == "weak" and c["unit"] == "GB/s" and c["dtype"] == "u8" and c["vs_baseline"] is None
+    assert [d["device"] for d in c["per_device"]] == [0, 1, 2, 3] and all(d["GBps"] > 0 and d["parts"] == 1 for d in c["per_device"])
+    assert c["n1_value"] > 0 and 0.15 < c["efficiency_vs_n_times_n1"] < 0.6  # four aliases of one GPU share it
+    assert abs(c["value"] - lines[0]["aggregate_payload_GBps"]) / c["value"] < 0.01
+

@@ -23,13 +23,17 @@ for mib in (16, 32, 64, 128, 256):
     out.append("%%6.2f ms %%5.1f GB/s" %% (best * 1e3, n / best / 1e9))
 print(" | ".join(out))
 """
-print("%-58s | " % "setting" + " | ".join("%3d MiB            " % m for m in (16, 32, 64, 128, 256)))
-# (split, smallest chunk MiB, pipelines, ramp KiB): a buffer is cut into ~split chunks of at least that size (and at most MODGPU_HOST_CHUNK_MB = 8);
-# each pipeline's first and last chunk are `ramp` KiB (0: all alike)
-DEFAULT = (32, 1, 8, 512)
-for split, cmin, pipes, ramp in (DEFAULT, (32, 1, 8, 0), (32, 1, 8, 256), (32, 1, 8, 1024), (16, 4, 8, 0), (16, 4, 8, 512), (32, 2, 8, 512), (64, 1, 8, 512), (64, 1, 8, 256),
-                                 (32, 1, 16, 512), (32, 1, 12, 512), (32, 1, 6, 512)):
-    env = dict(os.environ, MODGPU_REQUIRE_GPU="1", MODGPU_HOST_PIPES=str(pipes), MODGPU_HOST_SPLIT=str(split), MODGPU_HOST_CHUNK_MIN_MB=str(cmin), MODGPU_HOST_RAMP_KB=str(ramp))
+print("%-72s | " % "setting" + " | ".join("%3d MiB            " % m for m in (16, 32, 64, 128, 256)))
+# (split, smallest chunk MiB, pipelines, ramp KiB, lanes): a buffer is cut into ~split chunks of at least that size (and at most
+# MODGPU_HOST_CHUNK_MB = 8); each pipeline's first and last chunk are `ramp` KiB (0: all alike); a call's kernels across PCIe are queued
+# on `lanes` shared streams in launch order (0: a stream per slot -- round 3)
+DEFAULT = (32, 1, 8, 512, 2)
+ROUND3 = (16, 4, 8, 0, 0)
+for cfg in (DEFAULT, (32, 1, 8, 512, 0), (32, 1, 8, 512, 1), (32, 1, 8, 512, 4), (32, 1, 8, 0, 2), (32, 1, 8, 1024, 2), ROUND3, (16, 4, 8, 0, 2),
+            (32, 2, 8, 512, 2), (64, 1, 8, 512, 2), (64, 1, 8, 256, 2), (32, 1, 16, 512, 2), (32, 1, 4, 512, 2)):
+    split, cmin, pipes, ramp, lanes = cfg
+    env = dict(os.environ, MODGPU_REQUIRE_GPU="1", MODGPU_HOST_PIPES=str(pipes), MODGPU_HOST_SPLIT=str(split), MODGPU_HOST_CHUNK_MIN_MB=str(cmin),
+               MODGPU_HOST_RAMP_KB=str(ramp), MODGPU_HOST_LANES=str(lanes))
     r = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, env=env, timeout=600)
-    note = "  (default)" if (split, cmin, pipes, ramp) == DEFAULT else "  (round 3)" if (split, cmin, pipes, ramp) == (16, 4, 8, 0) else ""
-    print("%-58s | %s" % ("~%d chunks of >= %d MiB, %2d pipelines, ramp %4d KiB%s" % (split, cmin, pipes, ramp, note), r.stdout.strip() or r.stderr[-300:]), flush=True)
+    note = "  (default)" if cfg == DEFAULT else "  (round 3)" if cfg == ROUND3 else ""
+    print("%-72s | %s" % ("~%d chunks of >= %d MiB, %2d pipelines, ramp %4d KiB, %d lanes%s" % (split, cmin, pipes, ramp, lanes, note), r.stdout.strip() or r.stderr[-300:]), flush=True)
