@@ -38,7 +38,9 @@
  * Threading: callable concurrently from any number of host threads.  `device` selects the GPU
  * per call (-1 = the calling thread's current HIP device); no global "current device" is
  * relied on, and a call made with an explicit device leaves the calling thread's current HIP
- * device as it found it.  Host-buffer calls to the same device serialise on that device's staging context.
+ * device as it found it.  Host-buffer calls to the same device run side by side, each on staging slots of its own (a call
+ * that finds too few free takes fewer pipelines; one that finds none waits for a release).  The library keeps parked worker
+ * threads (per device for the staging pipelines, one pool for the host loop): started on first use, never joined.
  *
  * Environment (each read once, when first needed):
  *     MODGPU_REQUIRE_GPU=1       no host loop anywhere (see above)
@@ -49,10 +51,14 @@
  *                                fastest = per call, the engine the committed crossover table prices as faster for this
  *                                size and memory kind, the host loop with the threads it would really get
  *     MODGPU_HOST_ISA=name       host-loop body: generic | avx2 | avx512 (default: the best the CPU runs)
- *     MODGPU_HOST_THREADS=n      most host threads one host-loop call may use (default min(cores, 32))
- *     MODGPU_HOST_SPREAD=0       do not give each host-loop worker thread a CPU of its own (leave placement to the scheduler)
+ *     MODGPU_HOST_THREADS=n      most host threads one host-loop call may use (default min(cores, 32); never more than the
+ *                                control group's CPU quota or the caller's affinity mask allow)
+ *     MODGPU_HOST_SPREAD=0       do not bind each host-loop worker to a CPU of its own for the length of its span (leave placement to
+ *                                the scheduler).  The CPUs are taken from the CALLING thread's affinity mask at every call; the
+ *                                calling thread itself is never re-bound
  *     MODGPU_DEVICE_ALIAS=n      see modgpu_device_count
- *     MODGPU_HOST_PIPES / _CHUNK_MB / _ZEROCOPY_KB / _RING   staging pipeline of the host-buffer routes
+ *     MODGPU_HOST_PIPES / _CHUNK_MB / _CHUNK_MIN_MB / _SPLIT / _RAMP_KB / _LANES / _ZEROCOPY_KB / _RING
+ *                                staging pipelines of the host-buffer routes (modulate_amd/csrc/host_stream.cpp)
  *     MODGPU_NUMA=0              do not place host memory and worker threads next to their GPU
  *     MODGPU_HELPER_BELOW_MHZ=n  shader clock below which the helper workgroups of a large launch join in (default 1850; 0 = never)
  */
@@ -101,12 +107,20 @@ const char *modgpu_last_error(void);
  * that is already device-resident.  `dev_buf` may have any byte alignment (the reference's
  * callers pass buf+4).  Asynchronous on `hip_stream` (a hipStream_t; NULL = the device's
  * null stream); the caller synchronises.  This is the entry point the roofline is measured on.
- * Allocation-free and capturable into a hipGraph.  Any number of launches may be in flight at once, on any
- * streams, eager or replayed from graphs: the scheduling scratch of a large launch is never shared between two
- * launches that could overlap (a captured launch owns its scratch for good; an eager one gets scratch whose
- * previous user has finished, or a launch shape that needs none).  The one thing to avoid: two EXECUTABLE graphs
- * instantiated from the same capture and launched at the same time -- they replay the same node, scratch included
- * (one executable graph never overlaps itself; capture again for a second concurrent user). */
+ * Allocation-free and capturable into a hipGraph.  Any number of EAGER launches may be in flight at once, on any streams,
+ * beside any number of graph replays: the scheduling scratch of a large launch (a ticket counter) is never shared between
+ * two launches that could overlap -- an eager launch gets scratch whose previous user has finished, or a launch shape that
+ * needs none; a captured launch owns its scratch for good.
+ * What the CALLER of a captured launch must ensure: the same captured node must not run twice at the same time.  That means
+ * (a) do not launch one executable graph again -- on any stream -- while an earlier launch of it may still be running (CUDA
+ * orders such launches itself; HIP does not document that it does, so this library does not rely on it), and (b) do not
+ * launch two executable graphs instantiated from the same capture concurrently.  Both replay the same node, scratch
+ * included: the tickets of the two runs would interleave and bytes would come out wrong WITHOUT an error.  Capture again
+ * for every concurrent user.
+ * Captured large launches draw their scratch from a grow-only pool of 1 023 lines per device that is never handed out
+ * again (a graph may be replayed at any time).  A process that keeps re-capturing exhausts it; captures beyond that -- and a
+ * capture that is the device's very first large launch -- take the static streaming shape, which needs no scratch and is
+ * correct but ~7 % slower at 4 GiB.  modgpu_queue_stats (modgpu_testing.h) counts both. */
 int modgpu_cycle_device(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_off,
                         int device, void *hip_stream);
 
@@ -207,9 +221,13 @@ int modgpu_host_free(void *host_ptr);
  * cross PCIe to that GPU come from its own socket's DRAM.  modgpu_host_alloc_parts makes ONE contiguous buffer
  * for a list of parts laid end to end -- the concatenated buffer of CArk::LoadArkData / BuildArk (CArk.cpp:738,
  * 780) -- with part i's pages next to GPU i mod n_devices, the GPU modgpu_cycle_parts_host sends it to
- * (n_devices <= 0: all).  Where the topology is unknown, MODGPU_NUMA=0, or there is one node, both are
- * modgpu_host_alloc.  Free with modgpu_host_free.  Worker threads of the host-buffer routes run on their GPU's
- * node as well.  Placement is best effort and changes no result. */
+ * (n_devices <= 0: all).  With MODGPU_NUMA=0 or without a GPU both are modgpu_host_alloc.  Otherwise
+ * modgpu_host_alloc_parts always takes its own route -- reserve, bind each part's pages where its GPU's node is known (a part
+ * whose GPU's node cannot be read, e.g. no numa_node in a container's sysfs, is simply not bound), first-touch from several
+ * threads, page-lock in place -- because that route is also the faster way to get GB-sized page-locked memory (0.27 s against
+ * 0.43-0.51 s for 3.3 GB); modgpu_host_alloc_near falls back to modgpu_host_alloc when its one device's node is unknown.
+ * Free with modgpu_host_free.  Worker threads of the host-buffer routes run on their GPU's node as well.  Placement is
+ * best effort and changes no result. */
 int modgpu_host_alloc_near(void **host_ptr, uint64_t n, int device);
 int modgpu_host_alloc_parts(void **host_ptr, const uint64_t *sizes, int n_parts, int n_devices);
 /* NUMA node of the GPU behind `device`, -1 if unknown or placement is off. */

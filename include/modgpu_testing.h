@@ -79,6 +79,11 @@ int modgpu_host_trace_read(modgpu_host_trace_event_t *out, int cap);
  * while another was in flight (any device), out[4] = slots per device. */
 void modgpu_host_pool_stats(uint64_t out[5]);
 
+/* What shapes the host loop's threading in this process: out[0] = most threads per call (MODGPU_HOST_THREADS as latched),
+ * out[1] = the control group's CPU limit (cpu.max; 0 = none known), out[2] = CPUs in the calling thread's affinity mask,
+ * out[3] = parked worker threads started so far. */
+void modgpu_host_loop_info(uint64_t out[4]);
+
 /* modgpu_cycle_scalar_host with one named body ("generic", "avx2", "avx512"); MODGPU_ERR_INVALID if this CPU
  * does not run it.  Lets the tests compare every body with the oracle on one machine. */
 int modgpu_cycle_scalar_host_isa(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, const char *isa);

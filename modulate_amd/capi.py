@@ -95,6 +95,7 @@ TESTING_EXPORTS = {
     "modgpu_kernel_source_hash": (ctypes.c_char_p, []),
     "modgpu_host_tunables": (None, [ctypes.POINTER(_u64)]),
     "modgpu_host_chunking": (None, [ctypes.POINTER(_u64)]),
+    "modgpu_host_loop_info": (None, [ctypes.POINTER(_u64)]),
     "modgpu_host_trace": (None, [_int]),
     "modgpu_host_trace_read": (_int, [ctypes.POINTER(HostTraceEvent), _int]),
     "modgpu_host_pool_stats": (None, [ctypes.POINTER(_u64)]),

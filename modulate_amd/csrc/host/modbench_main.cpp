@@ -188,6 +188,12 @@ int HostCall()
     std::printf( "== per-call latency, caller-owned pageable host buffer (what CEncryptionCycler::Cycle gets): median of N calls\n" );
     std::printf( "   host loop body: %s   |   MODGPU_MIN_GPU_BYTES as latched: %llu   |   GPU %s\n", modgpu_host_loop_isa(),
                  (unsigned long long)modgpu_min_gpu_bytes(), gpu ? "present" : "ABSENT (host-loop column only)" );
+    {
+        uint64_t li[ 4 ];
+        modgpu_host_loop_info( li );
+        std::printf( "   host loop threads: at most %llu per call (MODGPU_HOST_THREADS), control-group CPU limit %llu (0 = none), %llu CPUs in this thread's affinity mask; policy above the threshold: %s\n",
+                     (unsigned long long)li[ 0 ], (unsigned long long)li[ 1 ], (unsigned long long)li[ 2 ], modgpu_host_policy() );
+    }
     std::printf( "   %10s  %14s  %14s  %10s\n", "bytes", "kernel (us)", "host loop (us)", "faster" );
     uint64_t crossover = 0;
     bool crossed = false;

@@ -1139,6 +1139,8 @@ int modgpu_gpu_required(void) { return gpu_required() ? 1 : 0; }
 
 uint64_t modgpu_min_gpu_bytes(void) { return min_gpu_bytes(); }
 
+void modgpu_host_loop_info(uint64_t out[4]) { modgpu_scalar_info(out); }
+
 const char *modgpu_host_policy(void) { return host_policy() == HostPolicy::Fastest ? "fastest" : "offload"; }
 
 int modgpu_host_policy_engine(uint64_t n, int pinned, double *host_us, double *kernel_us)

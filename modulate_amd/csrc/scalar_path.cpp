@@ -194,6 +194,8 @@ unsigned max_threads()
 unsigned cgroup_cpu_limit()
 {
     static const unsigned v = [] {
+        if (const char *e = std::getenv("MODGPU_HOST_CGROUP")) // MODGPU_HOST_CGROUP=0: do not look (short bursts are not throttled)
+            if (std::strcmp(e, "0") == 0) return 0u;
         auto read2 = [](const char *path, long long *a, long long *b) {
             FILE *f = std::fopen(path, "r");
             if (!f) return 0;
@@ -313,6 +315,13 @@ unsigned modgpu_scalar_threads_for(uint64_t n)
     return (unsigned)std::max<uint64_t>(t, 1);
 }
 unsigned long long modgpu_scalar_pool_threads() { return g_pool_threads.load(); }
+void modgpu_scalar_info(uint64_t out[4])
+{
+    out[0] = max_threads();
+    out[1] = cgroup_cpu_limit();
+    out[2] = allowed_cpus().size();
+    out[3] = g_pool_threads.load();
+}
 
 void modgpu_scalar_cycle(uint8_t *buf, uint64_t n, int32_t key, uint64_t stream_off, int isa)
 {
@@ -340,10 +349,14 @@ void modgpu_scalar_cycle(uint8_t *buf, uint64_t n, int32_t key, uint64_t stream_
     call->pos = pos;
     call->have_mask = sched_getaffinity(0, sizeof call->caller_mask, &call->caller_mask) == 0;
     if (spread_enabled() && cpus.size() >= call->count) {
-        // span i (when a worker draws it) -> the next allowed CPU that is not the caller's; concurrent calls start at different CPUs
-        static std::atomic<size_t> rotate{0};
-        size_t at = rotate.fetch_add((size_t)call->count, std::memory_order_relaxed);
+        // span i (when a worker draws it) -> the i-th allowed CPU AFTER the one the caller is on.  Neighbours of the caller's CPU
+        // are cores of its socket, next to the memory it most likely first-touched, and the same caller gets the same CPUs call
+        // after call; callers on different CPUs get different neighbourhoods.  (Round 3 rotated a global start index instead, so
+        // successive calls wandered over both sockets of the node: 34 GB/s at 64 MiB between 56 and 142 -- the "erratic rows".)
         const int here = sched_getcpu();
+        size_t at = 0;
+        for (size_t k = 0; k < cpus.size(); ++k)
+            if (cpus[k] == here) at = k + 1;
         call->cpus.resize((size_t)call->count, -1);
         for (uint64_t i = 0; i < call->count; ++i) {
             if (cpus[at % cpus.size()] == here) ++at;

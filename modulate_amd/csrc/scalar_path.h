@@ -14,3 +14,6 @@ bool modgpu_scalar_isa_usable(int isa);
 // one per 2 MiB, never more than the control group's CPU quota or the caller's affinity mask allow
 unsigned modgpu_scalar_threads_for(uint64_t n);
 unsigned long long modgpu_scalar_pool_threads(); // worker threads started so far (they park between calls)
+// out[0] = MODGPU_HOST_THREADS as latched, out[1] = the control group's CPU limit (0: none known), out[2] = CPUs in the calling
+// thread's affinity mask, out[3] = worker threads started so far
+void modgpu_scalar_info(uint64_t out[4]);

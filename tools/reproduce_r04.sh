@@ -23,6 +23,8 @@ staged)       # profiles/r04_staged_midsize.txt
     modulate_amd/bin/modbench --hostcall --trace > $O/r04_hostcall_trace.txt
     python3 tools/sweep_midsize_host.py > $O/r04_sweep_midsize_host.txt ;;
 crossover)    # profiles/r04_small_call_crossover.txt: both engines per call, the table MODGPU_HOST_POLICY=fastest decides by
-    modulate_amd/bin/modbench --hostcall > $O/r04_hostcall.txt ;;
+    modulate_amd/bin/modbench --hostcall > $O/r04_hostcall.txt
+    MODGPU_HOST_CGROUP=0 modulate_amd/bin/modbench --hostcall > $O/r04_hostcall_nocgroup.txt
+    MODGPU_HOST_SPREAD=0 modulate_amd/bin/modbench --hostcall > $O/r04_hostcall_nospread.txt ;;
 *) echo "usage: tools/reproduce_r04.sh build | tail | memside | staged | crossover" ;;
 esac

@@ -29,11 +29,25 @@ print("%-72s | " % "setting" + " | ".join("%3d MiB            " % m for m in (16
 # on `lanes` shared streams in launch order (0: a stream per slot -- round 3)
 DEFAULT = (32, 1, 8, 512, 2)
 ROUND3 = (16, 4, 8, 0, 0)
-for cfg in (DEFAULT, (32, 1, 8, 512, 0), (32, 1, 8, 512, 1), (32, 1, 8, 512, 4), (32, 1, 8, 0, 2), (32, 1, 8, 1024, 2), ROUND3, (16, 4, 8, 0, 2),
-            (32, 2, 8, 512, 2), (64, 1, 8, 512, 2), (64, 1, 8, 256, 2), (32, 1, 16, 512, 2), (32, 1, 4, 512, 2)):
+CONFIGS = (DEFAULT, (32, 1, 8, 512, 0), (32, 1, 8, 512, 1), (32, 1, 8, 512, 4), (32, 1, 8, 0, 2), (32, 1, 8, 0, 4), (32, 1, 8, 1024, 2), (32, 1, 8, 1024, 4), ROUND3,
+           (64, 1, 8, 256, 2), (64, 1, 8, 256, 4), (32, 1, 12, 512, 4), (32, 1, 16, 512, 4))
+# the box's CPU share drifts by +-10 % within minutes: every setting is run REPS times, the settings interleaved, and the best call of all is kept
+REPS = 3
+best = {cfg: None for cfg in CONFIGS}
+for rep in range(REPS):
+    for cfg in CONFIGS:
+        split, cmin, pipes, ramp, lanes = cfg
+        env = dict(os.environ, MODGPU_REQUIRE_GPU="1", MODGPU_HOST_PIPES=str(pipes), MODGPU_HOST_SPLIT=str(split), MODGPU_HOST_CHUNK_MIN_MB=str(cmin),
+                   MODGPU_HOST_RAMP_KB=str(ramp), MODGPU_HOST_LANES=str(lanes))
+        r = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, env=env, timeout=600)
+        try:
+            ms = [float(cell.split("ms")[0]) for cell in r.stdout.strip().split("|")]
+        except ValueError:
+            print(cfg, r.stdout, r.stderr[-300:])
+            continue
+        best[cfg] = ms if best[cfg] is None else [min(a, b) for a, b in zip(best[cfg], ms)]
+for cfg in CONFIGS:
     split, cmin, pipes, ramp, lanes = cfg
-    env = dict(os.environ, MODGPU_REQUIRE_GPU="1", MODGPU_HOST_PIPES=str(pipes), MODGPU_HOST_SPLIT=str(split), MODGPU_HOST_CHUNK_MIN_MB=str(cmin),
-               MODGPU_HOST_RAMP_KB=str(ramp), MODGPU_HOST_LANES=str(lanes))
-    r = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, env=env, timeout=600)
     note = "  (default)" if cfg == DEFAULT else "  (round 3)" if cfg == ROUND3 else ""
-    print("%-72s | %s" % ("~%d chunks of >= %d MiB, %2d pipelines, ramp %4d KiB, %d lanes%s" % (split, cmin, pipes, ramp, lanes, note), r.stdout.strip() or r.stderr[-300:]), flush=True)
+    cells = " | ".join("%6.2f ms %5.1f GB/s" % (t, (m << 20) / t / 1e6) for t, m in zip(best[cfg] or [], (16, 32, 64, 128, 256)))
+    print("%-72s | %s" % ("~%d chunks of >= %d MiB, %2d pipelines, ramp %4d KiB, %d lanes%s" % (split, cmin, pipes, ramp, lanes, note), cells), flush=True)
