@@ -53,9 +53,10 @@
  *     MODGPU_HOST_ISA=name       host-loop body: generic | avx2 | avx512 (default: the best the CPU runs)
  *     MODGPU_HOST_THREADS=n      most host threads one host-loop call may use (default min(cores, 32); never more than the
  *                                control group's CPU quota or the caller's affinity mask allow)
- *     MODGPU_HOST_SPREAD=0       do not bind each host-loop worker to a CPU of its own for the length of its span (leave placement to
- *                                the scheduler).  The CPUs are taken from the CALLING thread's affinity mask at every call; the
- *                                calling thread itself is never re-bound
+ *     MODGPU_HOST_SPREAD=1       bind each host-loop worker to a CPU of its own for the length of its span, taken from the CALLING
+ *                                thread's affinity mask at every call (default: the scheduler places the parked workers, which is
+ *                                faster for this memory-bound loop); the calling thread itself is never re-bound
+ *     MODGPU_HOST_CGROUP=0       do not cap the host loop's threads at the control group's CPU quota
  *     MODGPU_DEVICE_ALIAS=n      see modgpu_device_count
  *     MODGPU_HOST_PIPES / _CHUNK_MB / _CHUNK_MIN_MB / _SPLIT / _RAMP_KB / _LANES / _ZEROCOPY_KB / _RING
  *                                staging pipelines of the host-buffer routes (modulate_amd/csrc/host_stream.cpp)

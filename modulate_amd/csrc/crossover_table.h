@@ -10,16 +10,16 @@ namespace crossover {
 // kernel route, PAGEABLE caller memory (staged: memcpy -> pinned slot -> kernel across PCIe -> memcpy back)
 struct Point { uint64_t bytes; double gbps; };
 constexpr Point kKernelPageable[] = {
-    {4ull << 20, 11.0}, {8ull << 20, 14.7}, {16ull << 20, 17.6}, {32ull << 20, 21.5}, {64ull << 20, 29.4}, {256ull << 20, 34.7}, {1024ull << 20, 41.6}, {4096ull << 20, 43.0},
+    {4ull << 20, 16.6}, {8ull << 20, 22.1}, {16ull << 20, 26.6}, {32ull << 20, 29.7}, {64ull << 20, 33.7}, {128ull << 20, 38.9}, {256ull << 20, 41.0}, {1024ull << 20, 44.1}, {4096ull << 20, 44.0},
 };
 // kernel route, PAGE-LOCKED caller memory (modgpu_host_alloc / _register): one kernel across PCIe where the pages lie
 constexpr double kKernelPinnedGbps = 50.0;     // profiles/r02_sweep_pinned_routes.txt
 constexpr double kKernelCallOverheadUs = 14.0; // launch + wait before a byte moves (profiles/r02_ubench_latency.txt)
 // host loop, ONE thread, by body (generic, avx2, avx512), and what its threads reach together before DRAM is the bound
-constexpr double kHostThreadGbps[3] = {1.6, 8.5, 17.2};
-constexpr double kHostThreadsEfficiency = 0.75; // of threads x one thread's rate (measured 48 GB/s with 8 x 17.2 / 0.35 ...; see the profile)
-constexpr double kHostDramGbps = 150.0;
-constexpr double kHostWakeUs = 25.0; // waking parked workers and waiting for the last of them
+constexpr double kHostThreadGbps[3] = {1.6, 8.5, 17.4};
+constexpr double kHostThreadsEfficiency = 0.6; // of threads x one thread's rate: 8 threads 113 GB/s at 16 MiB (0.81), 16 threads 127 / 169 at 32 / 64 MiB (0.46 / 0.61)
+constexpr double kHostDramGbps = 170.0;        // 16 threads, 64 MiB ... 1 GiB: 145-180 GB/s
+constexpr double kHostWakeUs = 25.0;           // waking parked workers and waiting for the last of them
 
 inline double kernel_pageable_gbps(uint64_t n)
 {

@@ -227,21 +227,27 @@ std::vector<int> allowed_cpus()
         if (CPU_ISSET(c, &set)) cpus.push_back(c);
     return cpus;
 }
-bool spread_enabled() // MODGPU_HOST_SPREAD=0: leave the workers' placement to the scheduler
+// MODGPU_HOST_SPREAD=1: bind each worker to a CPU of its own for the length of its span.  OFF by default since round 4: the
+// workers are parked threads now, which the scheduler wakes on idle CPUs all over the caller's mask, and for this memory-bound
+// loop that is the better placement -- 16 unbound workers reach 113-180 GB/s at 16 MiB ... 1 GiB on the MI355X node's EPYC 9575F,
+// 16 workers bound to the CPUs next to the caller's 79-110 (neighbouring CPU numbers are cores of one or two CCDs, which share
+// a link into the memory fabric; profiles/r04_small_call_crossover.txt).  Round 3 bound them because its threads were started
+// per call, and short-lived threads the scheduler is left to place can sit on one CPU for their whole life (measured in a VM).
+bool spread_enabled()
 {
     static const bool v = [] {
         const char *e = std::getenv("MODGPU_HOST_SPREAD");
-        return !(e && std::strcmp(e, "0") == 0);
+        return e && std::strcmp(e, "1") == 0;
     }();
     return v;
 }
 
 // ---- parked workers ---------------------------------------------------------------------------------------------------------
 // One call's spans, drawn by the caller and by parked workers until none is left (round 3 started up to 31 std::threads per
-// call: ~30 us each, a millisecond for a 64 MiB buffer whose arithmetic takes a fifth of that).  Worker k of a call runs on
-// the k-th CPU the CALLER may use, skipping the one the caller is on: threads the scheduler is left to place can sit on one
-// CPU -- measured in a VM: 2 and 4 unpinned workers ran serially -- so a worker binds itself for the length of its span and
-// takes whatever mask the next call hands it.  The caller's own thread is never re-bound.
+// call: ~30 us each, a millisecond for a 64 MiB buffer whose arithmetic takes a fifth of that).  With MODGPU_HOST_SPREAD=1 worker k of a
+// call binds itself, for the length of its span, to the k-th CPU after the caller's in the CALLER's current affinity mask, and
+// takes whatever the next call hands it; by default workers stay where the scheduler wakes them (see spread_enabled).  The
+// caller's own thread is never re-bound.
 struct SpanCall {
     SpanFn span;
     uint8_t *buf;
