@@ -7,6 +7,14 @@ mkdir -p $O
 case "${1:-help}" in
 build)        # on the build box (cross-compiles without a GPU); the binaries travel with the snapshot
     make -s -C modulate_amd/csrc all && make -s -C tools tune_cycle ubench_queue_rw first_pass ;;
+bench)        # profiles/r04_bench.json, r04_* (rocprofv3 stats + PMC, replayed by bench.py as roofline.traffic), sizes, configs, batched parts
+    bash tools/profile.sh r04
+    python3 bench.py > $O/r04_bench.json
+    python3 tools/bench_sizes.py > $O/r04_bench_sizes.txt
+    python3 tools/bench_configs.py --out $O/r04_configs.json
+    python3 tools/bench_batch.py > $O/r04_bench_batch.txt
+    MODGPU_DEVICE_ALIAS=8 modulate_amd/bin/modbench --parts 8 --devices 0..7 --steps 5 > $O/r04_parts.txt
+    modulate_amd/bin/modbench --parts 1 --steps 20 >> $O/r04_parts.txt ;;
 tail)         # profiles/r04_tail.txt: where a sub-GiB launch's time goes, and the tail variants
     timeout -k 10 120 tools/tune_cycle selftest > $O/r04_selftest.txt
     for v in 0 1 2 3 4; do
@@ -26,5 +34,5 @@ crossover)    # profiles/r04_small_call_crossover.txt: both engines per call, th
     modulate_amd/bin/modbench --hostcall > $O/r04_hostcall.txt
     MODGPU_HOST_CGROUP=0 modulate_amd/bin/modbench --hostcall > $O/r04_hostcall_nocgroup.txt
     MODGPU_HOST_SPREAD=0 modulate_amd/bin/modbench --hostcall > $O/r04_hostcall_nospread.txt ;;
-*) echo "usage: tools/reproduce_r04.sh build | tail | memside | staged | crossover" ;;
+*) echo "usage: tools/reproduce_r04.sh build | bench | tail | memside | staged | crossover" ;;
 esac
