@@ -61,7 +61,8 @@
  *     MODGPU_HOST_PIPES / _CHUNK_MB / _CHUNK_MIN_MB / _SPLIT / _RAMP_KB / _LANES / _ZEROCOPY_KB / _RING
  *                                staging pipelines of the host-buffer routes (modulate_amd/csrc/host_stream.cpp)
  *     MODGPU_NUMA=0              do not place host memory and worker threads next to their GPU
- *     MODGPU_HELPER_BELOW_MHZ=n  shader clock below which the helper workgroups of a large launch join in (default 1850; 0 = never)
+ *     MODGPU_HELPER_BELOW_MHZ=n  shader clock below which the helper workgroups of a large launch join in (default: 77 % of the
+ *                                device's peak shader clock, 1 848 MHz on MI355X; 0 = never)
  */
 #ifndef MODGPU_H
 #define MODGPU_H

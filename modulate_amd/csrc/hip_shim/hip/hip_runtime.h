@@ -25,7 +25,7 @@ using hipEvent_t = ShimEvent *;
 enum hipStreamCaptureStatus : int { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
 enum hipStreamCaptureMode : int { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
 enum hipMemcpyKind : int { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
-enum hipDeviceAttribute_t : int { hipDeviceAttributeMultiprocessorCount = 63 };
+enum hipDeviceAttribute_t : int { hipDeviceAttributeMultiprocessorCount = 63, hipDeviceAttributeClockRate = 5 };
 constexpr unsigned hipStreamNonBlocking = 1, hipHostMallocPortable = 1, hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000, hipHostMallocDefault = 0,
                    hipHostRegisterPortable = 1, hipHostRegisterMapped = 2;
 

@@ -125,7 +125,7 @@ hipError_t hipGetDevice(int *d)
     *d = t_device;
     return hipSuccess;
 }
-hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 8; return hipSuccess; } // 8 "CUs": small grids, many trips
+hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int) { *v = a == hipDeviceAttributeClockRate ? 2400000 : 8; return hipSuccess; } // 8 "CUs": small grids, many trips
 hipError_t hipDeviceGetPCIBusId(char *buf, int len, int d) { std::snprintf(buf, (size_t)len, "0000:%02X:00.0", 0x10 + d); return hipSuccess; }
 hipError_t hipDeviceSynchronize() { null_stream()->drain(); return hipSuccess; }
 hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }

@@ -17,8 +17,9 @@ int CEncryptionCycler::GetDevice() { return t_device; }
 void CEncryptionCycler::Cycle( unsigned char* lpData, unsigned int liDataSize, int liInitialKey )
 {
     // stream offset 0: every Cycle call restarts the keystream (CEncryptionCycler.cpp:7).
-    // _auto_: the GPU kernel, and the library's host loop only where no GPU is usable -- the
-    // reference's Cycle returns void and cannot fail.
+    // _auto_: the size dispatch -- header-sized buffers on the library's host loop, larger ones on the
+    // GPU kernel, the host loop again where no GPU is usable: the reference's Cycle returns void and
+    // cannot fail.
     const int liStatus = modgpu_cycle_auto_host( lpData, liDataSize, liInitialKey, 0, t_device );
     if( liStatus != MODGPU_OK )
     {

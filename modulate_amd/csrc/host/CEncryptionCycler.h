@@ -13,10 +13,13 @@ class CEncryptionCycler
 {
 public:
     // In-place LCG-XOR of liDataSize bytes at lpData (a HOST pointer, any alignment), keystream
-    // restarted from liInitialKey -- bit-identical to the reference loop.  Computed on the MI355X;
-    // like the reference's, this Cycle cannot fail: on a host with no usable GPU the library's own
-    // host loop produces the same bytes (modgpu_cycle_auto_host).  The one exception is opt-in:
-    // with MODGPU_REQUIRE_GPU=1 in the environment a missing GPU throws std::runtime_error instead
+    // restarted from liInitialKey -- bit-identical to the reference loop.  Which engine computes is the
+    // size dispatch SURVEY 8b prescribes (modgpu_cycle_auto_host): buffers below MODGPU_MIN_GPU_BYTES
+    // (16 MiB by default -- every header the reference's three callers can pass) on the library's own
+    // host loop, larger ones on the MI355X (or wherever MODGPU_HOST_POLICY=fastest prices them faster).
+    // Like the reference's, this Cycle cannot fail: on a host with no usable GPU the host loop produces
+    // the same bytes at every size.  The one exception is opt-in: with MODGPU_REQUIRE_GPU=1 in the
+    // environment every size runs on the kernel and a missing GPU throws std::runtime_error instead
     // (test-suites and benchmarks set it so that nothing is ever measured on the wrong engine).
     void Cycle( unsigned char* lpData, unsigned int liDataSize, int liInitialKey );
 

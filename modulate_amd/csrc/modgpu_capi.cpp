@@ -222,8 +222,9 @@ constexpr int forced_variant() { return -1; }
 constexpr uint32_t forced_grid_cap() { return 0; }
 #endif
 
-// Streaming shape: one persistent 1024-thread workgroup per CU (4 waves/SIMD), so the grid is the
-// device's CU count (256 on MI355X), looked up once per device.
+// The device's CU count (256 on MI355X), looked up once per device: the grid of the static streaming shape (one persistent
+// 1024-thread workgroup per CU) and what the work-queue shape's grid is derived from (queue_grid: 25 main workgroups per
+// 32 CUs plus a helper on each CU they leave idle).
 uint32_t large_grid()
 {
     static std::mutex mu;
@@ -371,15 +372,33 @@ void queue_pair_unused(const QueuePair &q)
 // the 25-per-32 main workgroups stay HBM-bound down to ~1.7 GHz (profiles/r03_first_pass.txt: 1 711 MHz 6.97 TB/s, 1 645 6.87,
 // 1 579 6.69), and the steady-state clock sits at 2.0-2.2 GHz.  Thresholds from 1 600 to 1 950 MHz measure within run-to-run
 // spread of each other, back to back (r03_tune_dvfs.txt) and with host gaps between launches (bench.py's first-pass series,
-// A/B'd on one box: 1 850 a little better than 1 750 there, steady state identical); 1 850 keeps ~150 MHz off the steady state.
-constexpr uint32_t kHelperBelowMHzDefault = 1850;
-uint32_t helper_below_mhz() // MODGPU_HELPER_BELOW_MHZ (read once; 0 = helpers never join)
+// A/B'd on one box: 1 850 a little better than 1 750 there, steady state identical); ~1 850 keeps ~150 MHz off the steady state.
+// Round 4: the default is no longer a constant tuned on this pool's parts but a share of the device's own peak shader clock
+// (hipDeviceAttributeClockRate: 2 400 MHz on MI355X -> 1 848 MHz): 77 %.  MODGPU_HELPER_BELOW_MHZ still overrides it.
+constexpr uint32_t kHelperBelowMHzFallback = 1850;
+constexpr uint32_t kHelperBelowPercentOfPeak = 77;
+uint32_t helper_below_mhz() // MODGPU_HELPER_BELOW_MHZ (read once; 0 = helpers never join), else 77 % of the current device's peak clock
 {
-    static const uint32_t v = [] {
+    static const long forced = [] {
         const char *e = std::getenv("MODGPU_HELPER_BELOW_MHZ");
-        return e && *e ? (uint32_t)std::strtoul(e, nullptr, 0) : kHelperBelowMHzDefault;
+        return e && *e ? (long)std::strtoul(e, nullptr, 0) : -1L;
     }();
-    return v;
+    if (forced >= 0) return (uint32_t)forced;
+    static std::mutex mu;
+    static uint32_t by_dev[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return kHelperBelowMHzFallback;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!by_dev[dev]) {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, dev) != hipSuccess || khz < 500000 || khz > 5000000) {
+            (void)hipGetLastError();
+            by_dev[dev] = kHelperBelowMHzFallback;
+        } else {
+            by_dev[dev] = (uint32_t)((long long)khz / 1000 * kHelperBelowPercentOfPeak / 100);
+        }
+    }
+    return by_dev[dev];
 }
 #ifdef MODGPU_TESTING_HOOKS
 std::atomic<int> g_helper_mode{0}; // modgpu_debug_set_helpers: 0 by the clock, 1 always join, 2 no helper workgroups
@@ -397,9 +416,10 @@ constexpr int batch_mode() { return 0; }
 std::atomic<uint64_t> g_batch_launches{0}, g_batch_parts{0};
 
 constexpr uint32_t kSmallGridMax = 16384u;   // 4 KiB chunks: grid * 1 tile <= 65536
-// Hand-over between the two shapes, measured warm and cold (profiles/r01_tune_cycle_sizes*.txt):
-// up to 256 MiB the one-shot 4 KiB-chunk grid wins (launch cost ~3 us vs ~9 us, and the buffer fits
-// the 256 MiB Infinity Cache); beyond it the 128 KiB-burst streaming kernel does.
+// Hand-over between the small and the work-queue shape, measured warm and cold (profiles/r02_tune_cycle_sizes_cold.txt,
+// r03_handover.txt, and again in profiles/r04_tail.txt at 100 MB): up to 256 MiB the one-shot 4 KiB-chunk grid wins (a
+// launch's fixed cost is ~3 us against ~7 us, and a warm buffer sits in the 256 MiB Infinity Cache); beyond it the
+// work-queue streaming kernel (64 KiB chunks handed out by tickets) does.
 constexpr uint64_t kLargeMin = (256ull << 20) + 1;
 
 // Splits [buf, buf+n) into <16 head bytes, an aligned body of 16-byte words and <16 tail bytes,
