@@ -34,5 +34,10 @@ crossover)    # profiles/r04_small_call_crossover.txt: both engines per call, th
     modulate_amd/bin/modbench --hostcall > $O/r04_hostcall.txt
     MODGPU_HOST_CGROUP=0 modulate_amd/bin/modbench --hostcall > $O/r04_hostcall_nocgroup.txt
     MODGPU_HOST_SPREAD=0 modulate_amd/bin/modbench --hostcall > $O/r04_hostcall_nospread.txt ;;
-*) echo "usage: tools/reproduce_r04.sh build | bench | tail | memside | staged | crossover" ;;
+parity)       # profiles/r04_every_state.txt, r04_soak.txt
+    timeout -k 10 300 python3 tests/_every_state_child.py > $O/r04_every_state.txt
+    timeout -k 10 600 python3 tools/soak.py 240 11 > $O/r04_soak.txt ;;
+files)        # profiles/r04_file_routes.txt (incl. the I/O-only job with its source evicted from the caches: VERDICT r3 weak #8)
+    modulate_amd/bin/modbench --files /dev/shm > $O/r04_files.txt ;;
+*) echo "usage: tools/reproduce_r04.sh build | bench | tail | memside | staged | crossover | parity | files" ;;
 esac
