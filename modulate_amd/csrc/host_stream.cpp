@@ -524,8 +524,14 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
 
     // slot size: the whole buffer if it is small, else ~n/16 between 4 MiB and the cap (8 MiB by default:
     // profiles/r02_sweep_staged_routes.txt)
-    uint64_t chunk = n <= kChunkMin ? std::max<uint64_t>(n, 1ull << 20)
-                                    : std::min<uint64_t>(kChunk, std::max<uint64_t>(kChunkMin, ((n / kSplit) + 0xFFFFF) & ~0xFFFFFull));
+    // Memory on both sides: the round-4 schedule (~32 chunks of >= 1 MiB, ramped, kernels on shared lanes).  A FILE on either
+    // side keeps round 3's (~16 chunks of >= 4 MiB, all alike, a stream per slot): there the slow stage is pread / pwrite, which
+    // wants few large calls, and an interleaved A/B of both schedules on the file routes had the new one 3-5 % behind
+    // (profiles/r04_file_routes.txt).
+    const bool mem_both = src.mem && dst.mem;
+    const uint64_t split = mem_both ? kSplit : 16, chunk_min = mem_both ? kChunkMin : std::min<uint64_t>(4ull << 20, kChunk);
+    uint64_t chunk = n <= chunk_min ? std::max<uint64_t>(n, 1ull << 20)
+                                    : std::min<uint64_t>(kChunk, std::max<uint64_t>(chunk_min, ((n / split) + 0xFFFFF) & ~0xFFFFFull));
     chunk = std::min<uint64_t>(chunk, kChunk);
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
     Job job{src, dst, n, chunk, key, stream_off, false, false, {}, {}, {}, {}};
@@ -551,8 +557,8 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     SlotLease lease(s);
     lease.acquire(pipes * ring, ring);
     pipes = (int)lease.ids.size() / ring;
-    job.plan = cut_stream(n, chunk, pipes, kRamp);
-    for (int k = 0; k < kLanes && k < (int)lease.ids.size(); ++k) job.lanes.push_back(nullptr); // (streams exist after staging_reserve)
+    job.plan = cut_stream(n, chunk, pipes, mem_both ? kRamp : 0);
+    for (int k = 0; mem_both && k < kLanes && k < (int)lease.ids.size(); ++k) job.lanes.push_back(nullptr); // (streams exist after staging_reserve)
     trace(MODGPU_TRACE_SLOTS, -1, (uint64_t)pipes, chunk);
     rc = staging_reserve(s, lease.ids, chunk, !job.slot_kernel && !job.in_dst, !(src_direct && dst_direct) && !job.in_dst);
     if (rc) return rc;
