@@ -251,10 +251,14 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
 //         (1: halves, 2: quarters) -- a finer grain where the launch runs out of work, from the same single ticket counter.
 //         A piece is loaded with the chunk's U loads through a descriptor of the piece's size (the hardware drops the words
 //         beyond it) and only its U >> TSPLIT words are computed.
+// TLOOP = 1 (round 4, with TSPLIT >= 1, ONE part): the pieces are NOT handled inside the trip loop.  The trip loop runs over the whole
+//         chunks only, exactly as the product's (its index space ends at n_full); a workgroup whose next position lies beyond that
+//         falls into a SECOND, cold loop of the same shape over pieces -- same ticket counter, same mailbox protocol, the positions
+//         it already holds carried over -- so the finer grain at the tail costs the hot loop nothing but the branch at its exit.
 // TK    = 1 (round 4): the ticket is fetched at the START of a trip (in front of the load burst) and published in the same
 //         trip, so a workgroup is committed to one chunk fewer when the tickets run out (PREFIX = DEPTH + 1)
 template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int LAUX = AUX_NT, int B1 = 1, int B2 = 1,
-          int TSPLIT = 0, int TK = 0>
+          int TSPLIT = 0, int TK = 0, int TLOOP = 0>
 __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void lab_cycle_queue_kernel(LabQueueArgs la)
 {
     const CycleQueueArgs &a = la.q;
@@ -274,6 +278,9 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
     // index space: [0, n_full) whole chunks, then the tail chunks' pieces
     const uint32_t n_full = TSPLIT != 0 && la.tail_chunks < total_chunks ? total_chunks - la.tail_chunks : total_chunks;
     const uint32_t total = n_full + ((total_chunks - n_full) << TSPLIT);
+    constexpr bool INLOOP = TSPLIT != 0 && TLOOP == 0; // pieces handled by the trip loop itself (the first form measured)
+    static_assert(TLOOP == 0 || (TSPLIT >= 1 && DEPTH == 1 && MODE == MODE_FULL && TK == 0), "the cold tail loop exists for the product's loop shape");
+    const uint32_t limit_main = TLOOP != 0 ? n_full : total; // where the trip loop's index space ends
     // Two LDS words, used alternately: a trip's ticket is written before that trip's barrier and read after it, and
     // the same word is written again two trips later -- i.e. behind the NEXT trip's barrier, which no wave can reach
     // before it has done this trip's read.  (With a single word, correctness would lean on the other barrier, the
@@ -336,13 +343,13 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
         v.end = P.end;
         v.first = P.lead != 0 ? 1u : 0u;
         v.lo = a.start[p];
-        v.hi = TSPLIT != 0 ? total : a.start[p + 1];
+        v.hi = INLOOP ? total : TLOOP != 0 ? n_full : a.start[p + 1];
         v.lane_base = mulmod_canon(P.base_body, lane_mul);
     };
     // global index -> the part's chunk, and which piece of it (TSPLIT: pieces of CHUNK >> TSPLIT bytes beyond n_full)
     auto piece_of = [&](uint32_t g, const View &v, uint32_t *c, uint32_t *piece) {
         const uint32_t k = g - v.lo;
-        if (TSPLIT == 0 || k < n_full) {
+        if (!INLOOP || k < n_full) {
             *c = v.first + k;
             *piece = 0;
             return false;
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
         } else {
             uint32_t s[U];
             states(g, vs, s);
-            if (TSPLIT != 0 && g - vs.lo >= n_full) { // a piece: its words only (wave-uniform branch)
+            if (INLOOP && g - vs.lo >= n_full) { // a piece: its words only (wave-uniform branch)
 #pragma unroll
                 for (int u = 0; u < (U >> TSPLIT); ++u) d[u] = lab_cycle_word<ALG>(d[u], s[u]);
             } else {
@@ -469,11 +476,11 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
         for (int i = 0; i < NB; ++i) cq[i] = (uint32_t)PREFIX * Gm + t + (uint32_t)i;
         last_static = (uint32_t)PREFIX * Gm + t + (uint32_t)NB;
     }
-    if (active && cq[0] < total) {
+    bool publish = false; // the first trip has no ticket to publish yet
+    if (active && cq[0] < limit_main) {
         u32x4 d[NB][U];
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) load(d[i], cq[i]);
-        bool publish = false; // the first trip has no ticket to publish yet
         bool finished = false;
         while (!finished) {
 #pragma unroll
@@ -490,9 +497,90 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
                 for (int i = 0; i < DEPTH; ++i) cq[i] = cq[i + 1];
                 cq[DEPTH] = publish ? take_published() : last_static;
                 publish = true;
-                if (cq[0] >= total) {
+                if (cq[0] >= limit_main) {
                     finished = true;
                     break;
+                }
+            }
+        }
+    }
+    if constexpr (TLOOP != 0) {
+        // ---- the cold loop over the tail's pieces.  Positions >= n_full are pieces: h = position - n_full is piece (h mod 2^TSPLIT)
+        // of chunk n_full + (h >> TSPLIT).  cq[], `pending`, `publish`, the mailbox parity (`trip`) carry over from the trip loop:
+        // the protocol simply goes on, with W = U >> TSPLIT words per lane and trip.
+        constexpr int W = U >> TSPLIT;
+        constexpr uint32_t PIECE = CHUNK >> TSPLIT;
+        View wl{nullptr, 0, 0, 0, 0, 1}, ws{nullptr, 0, 0, 0, 0, 1};
+        auto locate_t = [&](View &v) { // (one part)
+            if (v.origin) return;
+            const CycleQueuePart &P = a.part[0];
+            v.origin = P.body - P.lead;
+            v.end = P.end;
+            v.first = P.lead != 0 ? 1u : 0u;
+            v.lo = 0;
+            v.hi = total;
+            v.lane_base = mulmod_canon(P.base_body, lane_mul);
+        };
+        auto where_t = [&](uint32_t g, const View &v, uint32_t *c, uint32_t *piece) {
+            const uint32_t h = g - n_full;
+            *c = v.first + n_full + (h >> TSPLIT);
+            *piece = h & ((1u << TSPLIT) - 1u);
+        };
+        auto rsrc_t = [&](uint32_t g, const View &v) {
+            uint32_t c, piece;
+            where_t(g, v, &c, &piece);
+            const uint64_t o = (uint64_t)c * CHUNK + (uint64_t)piece * PIECE;
+            const uint64_t left = g < total && o < v.end ? v.end - o : 0;
+            return __builtin_amdgcn_make_buffer_rsrc(v.origin + o, 0, (int)(left < PIECE ? left : PIECE), 0x00020000);
+        };
+        auto load_t = [&](u32x4(&d)[W], uint32_t g) {
+            locate_t(wl);
+            auto r = rsrc_t(g, wl);
+#pragma unroll
+            for (int u = 0; u < W; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, LAUX);
+        };
+        auto process_store_t = [&](u32x4(&d)[W], uint32_t g, bool pub) {
+            locate_t(ws);
+            auto r = rsrc_t(g, ws);
+            uint32_t c, piece, s[W];
+            where_t(g, ws, &c, &piece);
+            uint32_t pw = mulmod_canon(c_chunk_pow0<CHUNK>.v[c & 255], c_chunk_pow1<CHUNK>.v[(c >> 8) & 255]);
+            pw = mulmod_canon(pw, c_chunk_pow2<CHUNK>.v[(c >> 16) & 255]);
+            pw = mulmod_canon(pw, c_tile_lo.v[piece * (PIECE / 4096u)]); // a^(piece * piece bytes)  (entry 0 is 1)
+            s[0] = mulmod_canon(ws.lane_base, pw);
+#pragma unroll
+            for (int u = 1; u < W; ++u) s[u] = mulmod_canon(s[u - 1], lcg::kTileLo.v[BLOCK / 256]);
+#pragma unroll
+            for (int u = 0; u < W; ++u) d[u] = lab_cycle_word<ALG>(d[u], s[u]);
+            if (pub && tid == 0)
+                asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(q_next_lds + 4u * (trip & 1u)), "v"(pending) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            if (tid == 0) pending = __hip_atomic_fetch_add(a.queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < W; ++u) __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
+            ++trip;
+            stamp(trip);
+        };
+        if (active && cq[0] < total) { // (cq[0] >= n_full here: the trip loop has run out, or never had a chunk for this workgroup)
+            u32x4 e[2][W];
+            load_t(e[0], cq[0]);
+            bool finished = false;
+#pragma unroll 1
+            while (!finished) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    __builtin_amdgcn_s_barrier();
+                    load_t(e[(p + 1) % 2], cq[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    process_store_t(e[p], cq[0], publish);
+                    cq[0] = cq[1];
+                    cq[1] = publish ? take_published() : last_static;
+                    publish = true;
+                    if (cq[0] >= total) {
+                        finished = true;
+                        break;
+                    }
                 }
             }
         }

@@ -25,6 +25,16 @@ tail)         # profiles/r04_tail.txt: where a sub-GiB launch's time goes, and t
     timeout -k 10 400 tools/tune_cycle 411000000 7 > $O/r04_tune_411MB.txt
     timeout -k 10 400 tools/tune_cycle 104857600 7 1 > $O/r04_tune_100MB_cold.txt
     timeout -k 10 400 tools/tune_cycle 4294967296 3 > $O/r04_tune_4GiB.txt ;;
+tail2)        # profiles/r04_tail.txt, second part: the pieces in a second, cold loop (TLOOP)
+    for t in 100 200 400; do
+      timeout -k 10 120 tools/tune_cycle trace 411000000 200 1 5 $t 0 0 > $O/r04_trace_411MB_v5_t$t.txt
+      timeout -k 10 120 tools/tune_cycle trace 411000000 200 1 6 $t 0 0 > $O/r04_trace_411MB_v6_t$t.txt
+    done
+    timeout -k 10 120 tools/tune_cycle trace 411000000 200 1 0 0 0 0 > $O/r04_trace_411MB_v0_again.txt
+    timeout -k 10 400 tools/tune_cycle 411000000 7 > $O/r04_tune2_411MB.txt
+    timeout -k 10 400 tools/tune_cycle 104857600 7 1 > $O/r04_tune2_100MB_cold.txt
+    timeout -k 10 400 tools/tune_cycle 805306368 5 > $O/r04_tune2_768MiB.txt
+    timeout -k 10 400 tools/tune_cycle 4294967296 3 > $O/r04_tune2_4GiB.txt ;;
 memside)      # profiles/r04_memside_counters.json
     bash tools/memside_counters.sh 4294967296 ;;
 staged)       # profiles/r04_staged_midsize.txt
@@ -39,5 +49,5 @@ parity)       # profiles/r04_every_state.txt, r04_soak.txt
     timeout -k 10 600 python3 tools/soak.py 240 11 > $O/r04_soak.txt ;;
 files)        # profiles/r04_file_routes.txt (incl. the I/O-only job with its source evicted from the caches: VERDICT r3 weak #8)
     modulate_amd/bin/modbench --files /dev/shm > $O/r04_files.txt ;;
-*) echo "usage: tools/reproduce_r04.sh build | bench | tail | memside | staged | crossover | parity | files" ;;
+*) echo "usage: tools/reproduce_r04.sh build | bench | tail | tail2 | memside | staged | crossover | parity | files" ;;
 esac

@@ -50,11 +50,11 @@ template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = 16, int SYNC
 }
 
 // ALG: 2 = the shipped keystream sequence (canonicalising carry out of the fold, 3 instructions per byte), 1 = round 2's (4 per byte)
-template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int SAUX = 16, int LAUX = 2, int B1 = 1, int B2 = 1, int ALG = 2, int TSPLIT = 0, int TK = 0>
+template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int SAUX = 16, int LAUX = 2, int B1 = 1, int B2 = 1, int ALG = 2, int TSPLIT = 0, int TK = 0, int TLOOP = 0>
 void launch_queue(const LabArgs &a, uint32_t grid, hipStream_t st)
 {
     // (the kernel takes a table of parts: one buffer planned as a CycleArgs is a table of one)
-    hipLaunchKernelGGL((lab_cycle_queue_kernel<U, BLOCK, ALG, SAUX, TRACE, DEPTH, MODE, LAUX, B1, B2, TSPLIT, TK>), dim3(grid), dim3(BLOCK), 0, st,
+    hipLaunchKernelGGL((lab_cycle_queue_kernel<U, BLOCK, ALG, SAUX, TRACE, DEPTH, MODE, LAUX, B1, B2, TSPLIT, TK, TLOOP>), dim3(grid), dim3(BLOCK), 0, st,
                        lab_queue_args_of(a, (uint32_t)U * BLOCK * 16));
 }
 // the kernels the product ships, instantiated from the product header itself
@@ -145,7 +145,7 @@ static unsigned long long keystream_mismatches(const uint8_t *buf, uint64_t n, u
 // prints, relative to the earliest start: dispatch skew, the first trip (fill), steady-state trips, the
 // spread of finishing times (drain / imbalance), per XCD.
 // variant (queue schedule): 0 = the product's loop, 1 = TSPLIT 1 (halves over the last tail_chunks chunks), 2 = TSPLIT 2 (quarters),
-// 3 = TK (ticket fetched at the start of the trip), 4 = TK + TSPLIT 1.  cold: a 768 MB memset evicts the buffer from the
+// 3 = TK (ticket fetched at the start of the trip), 4 = TK + TSPLIT 1, 5 / 6 = TLOOP with halves / quarters (pieces in a second, cold loop).  cold: a 768 MB memset evicts the buffer from the
 // Infinity Cache before every traced launch (and nothing runs back to back in front of it).  dump: one line per workgroup.
 static int trace_main(uint64_t n, uint32_t grid_cap, bool queue, int variant, uint32_t tail_chunks, bool cold, bool dump)
 {
@@ -176,8 +176,10 @@ static int trace_main(uint64_t n, uint32_t grid_cap, bool queue, int variant, ui
         {"TSPLIT 2: tail chunks handed out as quarters", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 2, 0>, launch_queue<4, 1024, 1, 1, MODE_FULL, 18, 2, 1, 1, 2, 2, 0>},
         {"TK: ticket fetched at the start of the trip", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1>, launch_queue<4, 1024, 1, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1>},
         {"TK + TSPLIT 1", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 1, 1>, launch_queue<4, 1024, 1, 1, MODE_FULL, 18, 2, 1, 1, 2, 1, 1>},
+        {"TLOOP + TSPLIT 1: halves in a second, cold loop", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 1, 0, 1>, launch_queue<4, 1024, 1, 1, MODE_FULL, 18, 2, 1, 1, 2, 1, 0, 1>},
+        {"TLOOP + TSPLIT 2: quarters in a second, cold loop", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 2, 0, 1>, launch_queue<4, 1024, 1, 1, MODE_FULL, 18, 2, 1, 1, 2, 2, 0, 1>},
     };
-    if (variant < 0 || variant > 4) variant = 0;
+    if (variant < 0 || variant > 6) variant = 0;
     printf("== %s schedule%s%s, tail_chunks=%u, %s\n", queue ? "work-queue" : "static", queue ? ": " : "", queue ? kQueueVariants[variant].name : "", tail_chunks,
            cold ? "COLD (768 MB memset in front of each traced launch)" : "warm, back to back behind an untraced launch");
     const uint32_t base0 = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
@@ -553,6 +555,9 @@ int main(int argc, char **argv)
         for (uint32_t t : {g, 2 * g, 3 * g}) add_tail("TK + TSPLIT 1", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 1, 1>, t);
         add_tail("TK + TSPLIT 2", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 2, 1>, g / 2);
         add_tail("TSPLIT 1 over the WHOLE buffer (32 KiB pieces)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 1, 0>, 0xFFFFFFFFu);
+        // the pieces in a second, cold loop behind the trip loop (the trip loop itself as the product's)
+        for (uint32_t t : {g / 4, g / 2, g, 3 * g / 2, 2 * g, 3 * g}) add_tail("TLOOP halves in a cold second loop", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 1, 0, 1>, t);
+        for (uint32_t t : {g / 4, g / 2, g, 2 * g}) add_tail("TLOOP quarters in a cold second loop", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 2, 0, 1>, t);
     }
     LabArgs a{};
     CHECK(hipMalloc(&a.queue, 64));
