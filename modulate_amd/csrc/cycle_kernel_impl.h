@@ -357,9 +357,9 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
 // what differs is WHICH chunk a workgroup takes next.  With the static map (b, b+G, b+2G ...)
 // every workgroup does the same number of trips, but the CUs are not equally fast: the workgroups of every
 // other XCD take ~9.6 us per trip, the rest ~11 us (profiles/r02_trace_static_schedule.txt), so half the
-// chip idles at the end of every launch while the other half finishes.  Here a workgroup's first three
-// chunks are static (b, b+Gm, b+2Gm among the Gm main workgroups: no start-up latency) and every later one is a ticket from a global
-// counter, fetched a full trip before it is needed, so fast CUs simply take more chunks and all of them
+// chip idles at the end of every launch while the other half finishes.  Here a workgroup's first two
+// chunks are static (b, b+Gm among the Gm main workgroups: no start-up latency) and every later one is a ticket from a global
+// counter, fetched at the start of the trip before the one that loads it, so fast CUs simply take more chunks and all of them
 // finish within one trip of each other.
 //
 // The chunks on offer are those of a TABLE of parts (CycleQueueArgs, cycle_kernel.h): a global chunk index g belongs to the
@@ -370,10 +370,13 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
 // code, a handful of times per launch).  A view holds the part's base state already multiplied by this lane's share of the
 // jump (tile and lane powers), so a trip's first state is one multiply by the chunk's power, whatever the part.
 //
-// Ticket hand-off inside a workgroup: lane 0 issues the returning atomic right after a trip's second barrier
-// (in front of that trip's store burst, so waiting for it later never waits for those stores), publishes the
-// value through an LDS word (two, used alternately) before the NEXT trip's second barrier, and every wave reads it
-// after that barrier.  a.queue[0] is the ticket counter, a.queue[1] counts workgroups that are done; the last one out
+// Ticket hand-off inside a workgroup: lane 0 issues the returning atomic at the START of a trip (behind the first barrier,
+// in front of that trip's load burst, so waiting for it never waits for those loads), publishes the value through an LDS word
+// (two, used alternately) before the SAME trip's second barrier -- the trip's arithmetic, ~2 us, hides the atomic's round trip
+// -- and every wave reads it after that barrier: it is the chunk the NEXT trip loads.  (Until round 4 the atomic was issued
+// behind the second barrier and published a whole trip later: a workgroup was then committed to one chunk more when the
+// tickets ran out -- three instead of two -- and that chunk's worth of imbalance at the end of a launch cost 0.5 % at 4 GiB
+// and 0.8 % at 411 MB; profiles/r04_tail.txt, rows "TK".)  a.queue[0] is the ticket counter, a.queue[1] counts workgroups that are done; the last one out
 // zeroes both, so the pair is clean for the next launch without a memset, and then writes a.queue_seq to the host-visible
 // word a.queue_done: the host hands a pair to a new launch only after its previous user has signed off there.
 // One chunk of loads is in flight ahead of the one being computed (ping-pong); nt loads, sc1+nt stores; a workgroup barrier
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
     constexpr uint32_t CHUNK = (uint32_t)U * BLOCK * lcg::WORD;
     constexpr uint32_t SUB = BLOCK * lcg::WORD;
     constexpr int NB = DEPTH + 1;     // register buffers: one being computed, DEPTH being loaded
-    constexpr int PREFIX = DEPTH + 2; // static chunks per workgroup: a ticket fetched in trip j feeds trip j + PREFIX
+    constexpr int PREFIX = DEPTH + 1; // static chunks per workgroup: the ticket fetched in trip j is loaded in trip j + 1 and computed in trip j + PREFIX
     const uint32_t tid = threadIdx.x;
     const uint32_t blk = blockIdx.x;
     const uint32_t G = gridDim.x;
@@ -474,8 +477,8 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
         for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, AUX_NT);
     };
     // Lane 0's ticket traffic.  The returning atomic is a plain compiler-visible atomic, so the compiler counts it
-    // in its own s_waitcnt vmcnt(N) bookkeeping and waits for the value only where it is published, a trip
-    // later.  This needs the TU built with  -mllvm -amdgpu-atomic-optimizer-strategy=None : the default
+    // in its own s_waitcnt vmcnt(N) bookkeeping and waits for the value only where it is published, behind the
+    // trip's arithmetic (with the next chunk's loads, issued after it, still in flight).  This needs the TU built with  -mllvm -amdgpu-atomic-optimizer-strategy=None : the default
     // "atomic optimizer" rewrites it into a wave-aggregated atomic followed at once by s_waitcnt vmcnt(0),
     // i.e. the wave would sit out the atomic's round trip and every load it has in flight, each trip.
     // The LDS word is accessed with ds_write / ds_read in assembly: a volatile C++ access to a __shared__
@@ -483,19 +486,18 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
     uint32_t pending = 0; // lane 0: the ticket in flight
     const uint32_t q_next_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&q_next[0];
     const uint32_t one = 1u;
-    // one trip: chunk g's words are in d; compute, publish last trip's ticket, barrier, fetch a ticket, store burst
-    auto process_store = [&](u32x4(&d)[U], uint32_t g, bool publish) {
+    // one trip: chunk g's words are in d; compute, publish the ticket fetched at the start of this trip, barrier, store burst
+    auto process_store = [&](u32x4(&d)[U], uint32_t g) {
         locate(g, vs);
         auto r = rsrc_at(g, vs);
         uint32_t s[U];
         states(g, vs, s);
 #pragma unroll
         for (int u = 0; u < U; ++u) d[u] = cycle_word<ALG>(d[u], s[u]);
-        if (publish && tid == 0) // (the LDS write has landed before the barrier releases the readers)
+        if (tid == 0) // (the LDS write has landed before the barrier releases the readers)
             asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(q_next_lds + 4u * (trip & 1u)), "v"(pending) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        if (tid == 0) pending = __hip_atomic_fetch_add(a.queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int u = 0; u < U; ++u) __builtin_amdgcn_raw_buffer_store_b128(d[u], r, voff + u * SUB, 0, SAUX);
         ++trip;
@@ -506,16 +508,15 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
         return (uint32_t)PREFIX * Gm + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     };
 
-    // A workgroup's chunk sequence: positions 0 .. PREFIX-1 are static (b, b+Gm, ...), position j + PREFIX is the
+    // A workgroup's chunk sequence: positions 0 .. PREFIX-1 are static (b, b+Gm), position j + PREFIX is the
     // ticket fetched in trip j.  cq[] holds positions k .. k+DEPTH at the start of trip k: cq[0] is computed,
     // cq[DEPTH] is loaded now, the ones between are already in flight.
     uint32_t cq[NB];
-    uint32_t last_static; // position PREFIX-1, enters cq after trip 0
+    static_assert(PREFIX == NB, "the static positions are exactly the ones cq[] starts with");
     bool active = true;
     if (blk < Gm) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) cq[i] = blk + (uint32_t)i * Gm;
-        last_static = blk + (uint32_t)NB * Gm;
     } else {
         // A HELPER workgroup.  With the chip's clock where it normally is (2.1-2.2 GHz) the 25-per-32-CU main workgroups
         // saturate HBM and more streams only hurt (-1.8 % at one per CU).  For the first ~10 ms after load onset,
@@ -541,29 +542,28 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void m
         }
         __syncthreads();
         t = q_next[0];
-        __syncthreads(); // (the loop below writes q_next[0] again, two trips in)
+        __syncthreads(); // (the loop below writes q_next[0] again, in its first trip)
         active = t != 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < NB; ++i) cq[i] = (uint32_t)PREFIX * Gm + t + (uint32_t)i;
-        last_static = (uint32_t)PREFIX * Gm + t + (uint32_t)NB;
     }
     if (active && cq[0] < total) {
         u32x4 d[NB][U];
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) load(d[i], cq[i]);
-        bool publish = false; // the first trip has no ticket to publish yet
         bool finished = false;
         while (!finished) {
 #pragma unroll
             for (int p = 0; p < NB; ++p) {
                 __builtin_amdgcn_s_barrier();
+                // the ticket for the NEXT trip's load burst: fetched now, published behind this trip's arithmetic
+                if (tid == 0) pending = __hip_atomic_fetch_add(a.queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 load(d[(p + DEPTH) % NB], cq[DEPTH]);
                 __builtin_amdgcn_sched_barrier(0);
-                process_store(d[p], cq[0], publish);
+                process_store(d[p], cq[0]);
 #pragma unroll
                 for (int i = 0; i < DEPTH; ++i) cq[i] = cq[i + 1];
-                cq[DEPTH] = publish ? take_published() : last_static;
-                publish = true;
+                cq[DEPTH] = take_published();
                 if (cq[0] >= total) {
                     finished = true;
                     break;

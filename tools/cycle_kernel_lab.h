@@ -255,10 +255,11 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
 //         chunks only, exactly as the product's (its index space ends at n_full); a workgroup whose next position lies beyond that
 //         falls into a SECOND, cold loop of the same shape over pieces -- same ticket counter, same mailbox protocol, the positions
 //         it already holds carried over -- so the finer grain at the tail costs the hot loop nothing but the branch at its exit.
-// TK    = 1 (round 4): the ticket is fetched at the START of a trip (in front of the load burst) and published in the same
-//         trip, so a workgroup is committed to one chunk fewer when the tickets run out (PREFIX = DEPTH + 1)
+// TK    = 1 (round 4; the PRODUCT's since then): the ticket is fetched at the START of a trip (in front of the load burst) and
+//         published in the same trip, so a workgroup is committed to one chunk fewer when the tickets run out (PREFIX = DEPTH + 1).
+//         TK = 0: round 3's timing (fetched behind the second barrier, published a trip later)
 template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int LAUX = AUX_NT, int B1 = 1, int B2 = 1,
-          int TSPLIT = 0, int TK = 0, int TLOOP = 0>
+          int TSPLIT = 0, int TK = 1, int TLOOP = 0>
 __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void lab_cycle_queue_kernel(LabQueueArgs la)
 {
     const CycleQueueArgs &a = la.q;

@@ -35,6 +35,12 @@ tail2)        # profiles/r04_tail.txt, second part: the pieces in a second, cold
     timeout -k 10 400 tools/tune_cycle 104857600 7 1 > $O/r04_tune2_100MB_cold.txt
     timeout -k 10 400 tools/tune_cycle 805306368 5 > $O/r04_tune2_768MiB.txt
     timeout -k 10 400 tools/tune_cycle 4294967296 3 > $O/r04_tune2_4GiB.txt ;;
+tk)           # the product kernel with the ticket fetched at the start of the trip (TK): A/B against round 3's timing, the clock transient, parity
+    timeout -k 10 120 tools/tune_cycle selftest > $O/r04_tk_selftest.txt
+    for n in 411000000 805306368 4294967296; do timeout -k 10 400 tools/tune_cycle $n 7 > $O/r04_tk_tune_$n.txt; done
+    timeout -k 10 300 tools/tune_cycle dvfs 4294967296 16 > $O/r04_tk_dvfs.txt
+    python3 bench.py --no-cpu-baseline > $O/r04_tk_bench.json
+    python3 tools/bench_sizes.py > $O/r04_tk_bench_sizes.txt ;;
 memside)      # profiles/r04_memside_counters.json
     bash tools/memside_counters.sh 4294967296 ;;
 staged)       # profiles/r04_staged_midsize.txt
@@ -49,5 +55,5 @@ parity)       # profiles/r04_every_state.txt, r04_soak.txt
     timeout -k 10 600 python3 tools/soak.py 240 11 > $O/r04_soak.txt ;;
 files)        # profiles/r04_file_routes.txt (incl. the I/O-only job with its source evicted from the caches: VERDICT r3 weak #8)
     modulate_amd/bin/modbench --files /dev/shm > $O/r04_files.txt ;;
-*) echo "usage: tools/reproduce_r04.sh build | bench | tail | tail2 | memside | staged | crossover | parity | files" ;;
+*) echo "usage: tools/reproduce_r04.sh build | bench | tail | tail2 | tk | memside | staged | crossover | parity | files" ;;
 esac

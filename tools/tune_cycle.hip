@@ -50,7 +50,7 @@ template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = 16, int SYNC
 }
 
 // ALG: 2 = the shipped keystream sequence (canonicalising carry out of the fold, 3 instructions per byte), 1 = round 2's (4 per byte)
-template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int SAUX = 16, int LAUX = 2, int B1 = 1, int B2 = 1, int ALG = 2, int TSPLIT = 0, int TK = 0, int TLOOP = 0>
+template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int SAUX = 16, int LAUX = 2, int B1 = 1, int B2 = 1, int ALG = 2, int TSPLIT = 0, int TK = 1, int TLOOP = 0>
 void launch_queue(const LabArgs &a, uint32_t grid, hipStream_t st)
 {
     // (the kernel takes a table of parts: one buffer planned as a CycleArgs is a table of one)
@@ -317,6 +317,8 @@ static int dvfs_main(uint64_t n, int launches)
     struct Shape { const char *name; void (*launch)(const LabArgs &, uint32_t, hipStream_t); uint32_t grid; uint32_t main = 0; uint32_t below = 0; };
     const Shape shapes[] = {
         {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers joining below 1850 MHz (shipped)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1850},
+        {"the same with round 3's ticket timing (TK 0)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 0>, 256, 200, 1850},
+        {"PRODUCT kernel, 200 main + 56 helpers below 1850 MHz", launch_product_queue, 256, 200, 1850},
         {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers joining below 1750 MHz", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1750},
         {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers joining below 1900 MHz", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1900},
         {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers joining below 1600 MHz", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1600},
@@ -551,7 +553,8 @@ int main(int argc, char **argv)
         };
         for (uint32_t t : {g / 2, g, 2 * g, 3 * g, 4 * g}) add_tail("TSPLIT 1 (halves at the tail)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 1, 0>, t);
         for (uint32_t t : {g / 4, g / 2, g, 2 * g}) add_tail("TSPLIT 2 (quarters at the tail)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 2, 0>, t);
-        add_tail("TK (ticket at the start of the trip)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1>, 0);
+        add_tail("TK 1 (ticket at the start of the trip: product)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1>, 0);
+        add_tail("TK 0 (round 3: ticket published a trip later)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 0>, 0);
         for (uint32_t t : {g, 2 * g, 3 * g}) add_tail("TK + TSPLIT 1", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 1, 1>, t);
         add_tail("TK + TSPLIT 2", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 2, 1>, g / 2);
         add_tail("TSPLIT 1 over the WHOLE buffer (32 KiB pieces)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 1, 0>, 0xFFFFFFFFu);

@@ -1,7 +1,9 @@
 // tools/ubench_queue_rw.hip -- what the memory system gives the work-queue access pattern when it only reads, only
 // writes, or copies in place: the ceilings the cycle kernel (read + compute + write in place) sits under.
-// Same schedule as modgpu_cycle_queue_kernel (64 KiB chunks, 1024-thread workgroups, static prefix of 3 + tickets
-// fetched a trip ahead, nt loads, sc1 nt stores, both workgroup barriers), no arithmetic.
+// Same schedule as modgpu_cycle_queue_kernel (64 KiB chunks, 1024-thread workgroups, static prefix of 2 + tickets
+// fetched at the start of the trip before the one that loads them, nt loads, sc1 nt stores, both workgroup barriers), no arithmetic.
+// (profiles/r04_memside_counters.json and r02_ubench_queue_rw.txt were taken with round 3's ticket timing -- prefix of 3, the
+//  ticket published a trip later -- in all four kernels.)
 // Round 4: the fourth row is the PRODUCT kernel itself (modgpu_cycle_queue_kernel<4, 1024> from the product header), so that one
 // `rocprofv3 --pmc` pass over this program reads the memory-side counters of all four under the same conditions
 // (tools/memside_counters.sh, profiles/r04_memside_counters.json).
@@ -40,14 +42,13 @@ template <int MODE> __global__ __launch_bounds__(BLOCK) void rw_kernel(uint8_t *
             for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, 2);
         }
     };
-    auto process_store = [&](u32x4(&d)[U], uint32_t c, bool publish) {
+    auto process_store = [&](u32x4(&d)[U], uint32_t c) {
         auto r = rsrc_at(c);
 #pragma unroll
         for (int u = 0; u < U; ++u) d[u] = ~d[u];
-        if (publish && tid == 0) asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(lds + 4u * (trip & 1u)), "v"(pending) : "memory");
+        if (tid == 0) asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(lds + 4u * (trip & 1u)), "v"(pending) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        if (tid == 0) pending = __hip_atomic_fetch_add(queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if constexpr (MODE == READ) {
 #pragma unroll
             for (int u = 0; u < U; ++u) acc ^= d[u];
@@ -60,27 +61,27 @@ template <int MODE> __global__ __launch_bounds__(BLOCK) void rw_kernel(uint8_t *
     auto take = [&]() {
         uint32_t t;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(lds + 4u * ((trip - 1u) & 1u)) : "memory");
-        return 3u * G + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        return 2u * G + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     };
     uint32_t c0 = blk, c1 = blk + G;
-    const uint32_t c2 = blk + 2 * G;
+    auto fetch = [&]() { if (tid == 0) pending = __hip_atomic_fetch_add(queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     if (c0 < n_chunks) {
         u32x4 d0[U], d1[U];
         load(d0, c0);
-        bool publish = false;
         while (true) {
             __builtin_amdgcn_s_barrier();
+            fetch();
             load(d1, c1);
             __builtin_amdgcn_sched_barrier(0);
-            process_store(d0, c0, publish);
+            process_store(d0, c0);
             c0 = c1;
-            c1 = publish ? take() : c2;
-            publish = true;
+            c1 = take();
             if (c0 >= n_chunks) break;
             __builtin_amdgcn_s_barrier();
+            fetch();
             load(d0, c1);
             __builtin_amdgcn_sched_barrier(0);
-            process_store(d1, c0, true);
+            process_store(d1, c0);
             c0 = c1;
             c1 = take();
             if (c0 >= n_chunks) break;
