@@ -18,7 +18,7 @@
 // Three launch shapes (cycle_kernel.h):
 //   queue   what the roofline is measured on (buffers > 256 MiB): persistent 1024-thread workgroups, 25 per 32 CUs,
 //           64 KiB chunks on absolute 64 KiB-aligned addresses handed out by a ticket counter (a static prefix of
-//           three, then tickets fetched a trip ahead), so fast and slow XCDs finish together; the next chunk's
+//           two, then tickets fetched at the start of the trip before the one that loads them), so fast and slow XCDs finish together; the next chunk's
 //           four loads are in flight while this one is computed; loads and stores are issued as
 //           workgroup-synchronous bursts (nt loads, sc1+nt stores).  The {ticket, done} pair is cleaned by the last
 //           workgroup out, which then signs off in a host-visible word so the host never hands a pair to two

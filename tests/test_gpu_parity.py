@@ -422,8 +422,8 @@ def test_fuzz_forced_shapes(gpu_t, oracle, case):
         chunk = {"small": 4096, "large": 131072, "queue": 65536}[shape]
         sizes = [0, 1, 15, 16, 17, chunk - 16, chunk, chunk + 16, 2 * chunk, 2 * chunk + 5, 3 * chunk - 1, 5 * chunk + 123]
         sizes += [int(x) for x in rng.integers(0, 6 << 20, size=14)]
-        if shape == "queue":  # static prefix (3 chunks per workgroup) + ticketed chunks, many trips per workgroup
-            sizes += [3 * chunk, 4 * chunk, 4 * chunk + 1, 7 * chunk - 16, 40 * chunk + 77]
+        if shape == "queue":  # static prefix (2 chunks per workgroup; 3 until round 4) + ticketed chunks, many trips per workgroup
+            sizes += [2 * chunk + 1, 3 * chunk, 4 * chunk, 4 * chunk + 1, 7 * chunk - 16, 40 * chunk + 77]
         for n in sizes:
             base = int(rng.integers(0, 4096)) if n % 3 else int(rng.integers(0, 300000))
             base = min(base, cap - n - 64)
