@@ -38,8 +38,9 @@ def _san_lib_cases(preload, lib, extra_env):
     O.build(ref=False)  # here, not in the child: the compiler must not run under a preloaded sanitizer runtime
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "modulate_amd", "csrc"), "sanitize-lib"])
     env = dict(os.environ, LD_PRELOAD=preload, MODGPU_LIB=os.path.join(ROOT, "modulate_amd", "_san", lib),
-               MODGPU_SHIM_DEVICES="8", MODGPU_HOST_CHUNK_MB="1", MODGPU_REQUIRE_GPU="0", MODGPU_MIN_GPU_BYTES="65536", **extra_env)
-    for k in ("MODGPU_HOST_PIPES", "MODGPU_HOST_ZEROCOPY_KB", "MODGPU_DEVICE_ALIAS"):
+               MODGPU_SHIM_DEVICES="8", MODGPU_HOST_CHUNK_MB="1", MODGPU_HOST_RAMP_KB="256", MODGPU_REQUIRE_GPU="0", MODGPU_MIN_GPU_BYTES="65536", **extra_env)
+    # (1 MiB slots and a 256 KiB ramp: buffers of 12 MiB and up take the ramped plan -- small first / last chunk per pipeline -- on few MiB)
+    for k in ("MODGPU_HOST_PIPES", "MODGPU_HOST_ZEROCOPY_KB", "MODGPU_DEVICE_ALIAS", "MODGPU_HOST_SPLIT", "MODGPU_HOST_CHUNK_MIN_MB", "MODGPU_HOST_LANES"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "san_lib_cases.py"), "-x", "-q", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=ROOT, timeout=1500)
