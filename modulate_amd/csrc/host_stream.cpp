@@ -33,6 +33,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <immintrin.h>
 #include <time.h>
 
 #include <algorithm>
@@ -208,11 +209,43 @@ int staging_reserve(Staging &s, const std::vector<int> &ids, uint64_t need, bool
     return MODGPU_OK;
 }
 
+// ---- the staging copies ------------------------------------------------------------------------------------------------------
+// What bounds the staged route since round 4 is its two CPU copies of every byte (profiles/r04_staged_midsize.txt): ~10 GB/s per
+// thread, because both are DRAM-miss streams -- and a plain memcpy of a few MiB also READS every destination line before it
+// overwrites it (write-allocate).  A copy with non-temporal stores does not: two DRAM streams instead of three.  The bytes are
+// not wanted in this core's cache anyway -- the slot is read next by the GPU across PCIe, the caller's buffer by whoever comes next.
+// MODGPU_HOST_NTCOPY=0 falls back to memcpy (read once).
+const bool kNtCopy = env_int("MODGPU_HOST_NTCOPY", 1, 0, 1) != 0;
+__attribute__((target("avx2"))) void copy_nt_avx2(uint8_t *dst, const uint8_t *src, uint64_t n)
+{
+    // head: up to the first 32-byte boundary of dst
+    const uint64_t head = std::min<uint64_t>(n, (32 - (reinterpret_cast<uintptr_t>(dst) & 31)) & 31);
+    std::memcpy(dst, src, head);
+    dst += head, src += head, n -= head;
+    uint64_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i)), b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 32)),
+                      c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 64)), d = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 96), d);
+    }
+    _mm_sfence(); // the streamed lines are globally visible before the kernel is launched / the call returns
+    std::memcpy(dst + i, src + i, n - i);
+}
+void copy_bytes(uint8_t *dst, const uint8_t *src, uint64_t n)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (kNtCopy && avx2 && n >= (256u << 10)) copy_nt_avx2(dst, src, n);
+    else std::memcpy(dst, src, n);
+}
+
 // `len` bytes at offset `off` of the source -> to[0 .. len)
 int fill_slot(const Endpoint &src, uint8_t *to, uint64_t off, uint64_t len)
 {
     if (src.mem) {
-        std::memcpy(to, src.mem + off, len);
+        copy_bytes(to, src.mem + off, len);
         return MODGPU_OK;
     }
     for (uint64_t done = 0; done < len;) {
@@ -228,7 +261,7 @@ int fill_slot(const Endpoint &src, uint8_t *to, uint64_t off, uint64_t len)
 int drain_slot(const Endpoint &dst, const uint8_t *pinned, uint64_t off, uint64_t len)
 {
     if (dst.mem) {
-        std::memcpy(dst.mem + off, pinned, len);
+        copy_bytes(dst.mem + off, pinned, len);
         return MODGPU_OK;
     }
     for (uint64_t done = 0; done < len;) {

@@ -23,22 +23,23 @@ for mib in (16, 32, 64, 128, 256):
     out.append("%%6.2f ms %%5.1f GB/s" %% (best * 1e3, n / best / 1e9))
 print(" | ".join(out))
 """
-print("%-72s | " % "setting" + " | ".join("%3d MiB            " % m for m in (16, 32, 64, 128, 256)))
+print("%-84s | " % "setting" + " | ".join("%3d MiB            " % m for m in (16, 32, 64, 128, 256)))
 # (split, smallest chunk MiB, pipelines, ramp KiB, lanes): a buffer is cut into ~split chunks of at least that size (and at most
 # MODGPU_HOST_CHUNK_MB = 8); each pipeline's first and last chunk are `ramp` KiB (0: all alike); a call's kernels across PCIe are queued
 # on `lanes` shared streams in launch order (0: a stream per slot -- round 3)
-DEFAULT = (32, 1, 8, 512, 2)
-ROUND3 = (16, 4, 8, 0, 0)
-CONFIGS = (DEFAULT, (32, 1, 8, 512, 0), (32, 1, 8, 512, 1), (32, 1, 8, 512, 4), (32, 1, 8, 0, 2), (32, 1, 8, 0, 4), (32, 1, 8, 1024, 2), (32, 1, 8, 1024, 4), ROUND3,
-           (64, 1, 8, 256, 2), (64, 1, 8, 256, 4), (32, 1, 12, 512, 4), (32, 1, 16, 512, 4))
+DEFAULT = (32, 1, 8, 1024, 2, 1)
+ROUND3 = (16, 4, 8, 0, 0, 0)
+# (..., nt): 1 = the staging copies use non-temporal stores (default), 0 = plain memcpy
+CONFIGS = (DEFAULT, (32, 1, 8, 1024, 2, 0), (32, 1, 8, 1024, 4, 1), (32, 1, 8, 512, 2, 1), (32, 1, 8, 0, 2, 1), (32, 1, 8, 1024, 0, 1), (16, 4, 8, 0, 0, 1), ROUND3,
+           (64, 1, 8, 256, 2, 1), (32, 1, 12, 1024, 2, 1), (32, 1, 16, 1024, 4, 1))
 # the box's CPU share drifts by +-10 % within minutes: every setting is run REPS times, the settings interleaved, and the best call of all is kept
 REPS = 3
 best = {cfg: None for cfg in CONFIGS}
 for rep in range(REPS):
     for cfg in CONFIGS:
-        split, cmin, pipes, ramp, lanes = cfg
+        split, cmin, pipes, ramp, lanes, nt = cfg
         env = dict(os.environ, MODGPU_REQUIRE_GPU="1", MODGPU_HOST_PIPES=str(pipes), MODGPU_HOST_SPLIT=str(split), MODGPU_HOST_CHUNK_MIN_MB=str(cmin),
-                   MODGPU_HOST_RAMP_KB=str(ramp), MODGPU_HOST_LANES=str(lanes))
+                   MODGPU_HOST_RAMP_KB=str(ramp), MODGPU_HOST_LANES=str(lanes), MODGPU_HOST_NTCOPY=str(nt))
         r = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, env=env, timeout=600)
         try:
             ms = [float(cell.split("ms")[0]) for cell in r.stdout.strip().split("|")]
@@ -47,7 +48,7 @@ for rep in range(REPS):
             continue
         best[cfg] = ms if best[cfg] is None else [min(a, b) for a, b in zip(best[cfg], ms)]
 for cfg in CONFIGS:
-    split, cmin, pipes, ramp, lanes = cfg
+    split, cmin, pipes, ramp, lanes, nt = cfg
     note = "  (default)" if cfg == DEFAULT else "  (round 3)" if cfg == ROUND3 else ""
     cells = " | ".join("%6.2f ms %5.1f GB/s" % (t, (m << 20) / t / 1e6) for t, m in zip(best[cfg] or [], (16, 32, 64, 128, 256)))
-    print("%-72s | %s" % ("~%d chunks of >= %d MiB, %2d pipelines, ramp %4d KiB, %d lanes%s" % (split, cmin, pipes, ramp, lanes, note), cells), flush=True)
+    print("%-84s | %s" % ("~%d chunks of >= %d MiB, %2d pipelines, ramp %4d KiB, %d lanes, %s%s" % (split, cmin, pipes, ramp, lanes, "NT copies" if nt else "memcpy", note), cells), flush=True)
