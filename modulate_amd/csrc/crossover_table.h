@@ -1,6 +1,7 @@
 // crossover_table.h -- what MODGPU_HOST_POLICY=fastest decides by: the two engines' measured rates for a caller-owned HOST
 // buffer on the node class this library is tuned on (MI355X behind PCIe gen 5 x16, 2 x EPYC 9575F), from
-// profiles/r04_small_call_crossover.txt (bin/modbench --hostcall; re-measure there and edit here for another host).
+// profiles/r04_small_call_crossover.txt and r04_staged_midsize.txt (bin/modbench --hostcall, tools/sweep_midsize_host.py; re-measure
+// there and edit here for another host).
 // Payload GB/s, one call, warm.  Not used by the default policy (offload), which only has the size threshold.
 #pragma once
 #include <cstdint>
@@ -10,7 +11,7 @@ namespace crossover {
 // kernel route, PAGEABLE caller memory (staged: memcpy -> pinned slot -> kernel across PCIe -> memcpy back)
 struct Point { uint64_t bytes; double gbps; };
 constexpr Point kKernelPageable[] = {
-    {4ull << 20, 16.6}, {8ull << 20, 22.1}, {16ull << 20, 26.6}, {32ull << 20, 29.7}, {64ull << 20, 33.7}, {128ull << 20, 38.9}, {256ull << 20, 41.0}, {1024ull << 20, 44.1}, {4096ull << 20, 44.0},
+    {4ull << 20, 16.6}, {8ull << 20, 22.1}, {16ull << 20, 30.0}, {32ull << 20, 31.4}, {64ull << 20, 35.5}, {128ull << 20, 39.6}, {256ull << 20, 41.7}, {1024ull << 20, 44.1}, {4096ull << 20, 45.0},
 };
 // kernel route, PAGE-LOCKED caller memory (modgpu_host_alloc / _register): one kernel across PCIe where the pages lie
 constexpr double kKernelPinnedGbps = 50.0;     // profiles/r02_sweep_pinned_routes.txt

@@ -97,11 +97,13 @@ const int kRing = env_int("MODGPU_HOST_RING", 4, 2, 4);
 //   MODGPU_HOST_CHUNK_MIN_MB  ... of at least this many MiB (and at most MODGPU_HOST_CHUNK_MB)
 //   MODGPU_HOST_RAMP_KB     each pipeline's FIRST and LAST chunk are this small (0 = all chunks alike): nothing crosses the link
 //                           while the first chunks are being copied in, nor while the last ones are copied out
-// Defaults from profiles/r04_staged_midsize.txt (16 ... 256 MiB, pageable, settings interleaved, best of 18 calls each): ~32 chunks of
-// >= 1 MiB, a 1 MiB ramp and two lanes are at or within 5 % of the best row at every size (round 3: ~16 chunks of >= 4 MiB, no
-// ramp, a stream per slot); the timeline there shows why the ramp and the lanes exist.
-const uint64_t kSplit = (uint64_t)env_int("MODGPU_HOST_SPLIT", 32, 2, 256);
-const uint64_t kChunkMin = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_CHUNK_MIN_MB", 1, 1, 256) << 20, kChunk);
+// Defaults from profiles/r04_staged_midsize.txt (16 ... 256 MiB, pageable, settings interleaved, best of 18 calls each): ~16 chunks of
+// >= 2 MiB behind a 1 MiB ramp, two lanes and non-temporal copies are at or within 4 % of the best row at every size (round 3: ~16
+// chunks of >= 4 MiB, no ramp, a stream per slot, memcpy); the timelines there show why the ramp, the lanes and the copies exist.
+// (Before the copies were fast, finer chunks -- ~32 of >= 1 MiB -- measured best; with them a chunk's kernel is the longer stage, and
+// a kernel of 2-4 MiB uses the link better than one of 1 MiB.)
+const uint64_t kSplit = (uint64_t)env_int("MODGPU_HOST_SPLIT", 16, 2, 256);
+const uint64_t kChunkMin = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_CHUNK_MIN_MB", 2, 1, 256) << 20, kChunk);
 const uint64_t kRamp = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_RAMP_KB", 1024, 0, 1 << 18) << 10, kChunk);
 //   MODGPU_HOST_LANES       streams a call's kernels-across-PCIe are queued on, in launch order, round robin (0 = every slot its
 //                           own stream, the round-3 form).  With a stream per slot the GPU runs all 16 chunk kernels of a call at
