@@ -785,15 +785,20 @@ TUNABLES = [{"MODGPU_HOST_PIPES": "1"}, {"MODGPU_HOST_PIPES": "2"}, {"MODGPU_HOS
             {"MODGPU_HOST_ZEROCOPY_KB": "0"}, {"MODGPU_HOST_RING": "2"},
             # a zero-copy limit above the slot size used to overrun the pinned staging buffer
             {"MODGPU_HOST_CHUNK_MB": "1", "MODGPU_HOST_ZEROCOPY_KB": "2048"},
-            {"MODGPU_HOST_PIPES": "16", "MODGPU_HOST_CHUNK_MB": "1"}]
+            {"MODGPU_HOST_PIPES": "16", "MODGPU_HOST_CHUNK_MB": "1"},
+            # round 4's knobs off their defaults: no lanes (a stream per slot), one lane, no ramp, a ramp as large as a chunk, plain memcpy,
+            # many small chunks, few large ones
+            {"MODGPU_HOST_LANES": "0"}, {"MODGPU_HOST_LANES": "1", "MODGPU_HOST_RAMP_KB": "0"}, {"MODGPU_HOST_RAMP_KB": "64", "MODGPU_HOST_LANES": "8"},
+            {"MODGPU_HOST_NTCOPY": "0", "MODGPU_HOST_RAMP_KB": "4096"}, {"MODGPU_HOST_SPLIT": "200", "MODGPU_HOST_CHUNK_MIN_MB": "1"},
+            {"MODGPU_HOST_SPLIT": "2", "MODGPU_HOST_CHUNK_MIN_MB": "8", "MODGPU_HOST_CHUNK_MB": "32"}]
 
 
 @pytest.mark.parametrize("env", TUNABLES, ids=lambda e: ",".join(f"{k[12:]}={v}" for k, v in e.items()))
 def test_host_path_tunables(gpu, env):
-    """MODGPU_HOST_PIPES / _CHUNK_MB / _ZEROCOPY_KB / _RING off their defaults, on the chunk-boundary sizes,
-    pageable and pinned caller memory, encrypt + decrypt, whole-buffer compare against the oracle."""
+    """MODGPU_HOST_PIPES / _CHUNK_MB / _ZEROCOPY_KB / _RING / _LANES / _RAMP_KB / _NTCOPY / _SPLIT / _CHUNK_MIN_MB off their defaults, on the
+    chunk-boundary sizes, pageable and pinned caller memory, encrypt + decrypt, whole-buffer compare against the oracle."""
     sizes = [4097, (1 << 20) + 1, (2 << 20) - 1] + list(HOST_PATH_SIZES[:4])
-    if env.get("MODGPU_HOST_CHUNK_MB") == "64" or env.get("MODGPU_HOST_PIPES") in ("4", "16"):
+    if env.get("MODGPU_HOST_CHUNK_MB") == "64" or env.get("MODGPU_HOST_PIPES") in ("4", "16") or "MODGPU_HOST_LANES" in env or "MODGPU_HOST_SPLIT" in env:
         sizes.append(HOST_PATH_SIZES[4])
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-c", _TUNABLE_CHILD % (ROOT, sizes)], capture_output=True, text=True, env=e, timeout=900)
