@@ -55,5 +55,10 @@ parity)       # profiles/r04_every_state.txt, r04_soak.txt
     timeout -k 10 600 python3 tools/soak.py 240 11 > $O/r04_soak.txt ;;
 files)        # profiles/r04_file_routes.txt (incl. the I/O-only job with its source evicted from the caches: VERDICT r3 weak #8)
     modulate_amd/bin/modbench --files /dev/shm > $O/r04_files.txt ;;
-*) echo "usage: tools/reproduce_r04.sh build | bench | tail | tail2 | tk | memside | staged | crossover | parity | files" ;;
+extras)       # profiles/r04_first_pass.txt, r04_bench_big.txt, r04_handover.txt: round 3's tables re-taken on the final build
+    for p in h2d fill; do timeout -k 10 120 tools/first_pass series 4294967296 16 $p > $O/r04_series_$p.txt; done
+    timeout -k 10 400 tools/first_pass first > $O/r04_first.txt
+    timeout -k 10 600 python3 tools/bench_big.py > $O/r04_bench_big.txt
+    timeout -k 10 300 python3 tools/handover.py > $O/r04_handover.txt ;;
+*) echo "usage: tools/reproduce_r04.sh build | bench | tail | tail2 | tk | memside | staged | crossover | parity | files | extras" ;;
 esac
