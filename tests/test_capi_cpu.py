@@ -412,6 +412,42 @@ def test_kernel_codegen_guard_passes_the_tree_and_rejects_a_broken_build():
     assert rule.index("check_isa.py cycle_kernel.s") < rule.index("-c cycle_kernel.hip")
 
 
+def test_lab_kernel_at_the_products_settings_is_the_products_loop():
+    """tools/cycle_kernel_lab.h repeats the work-queue kernel with its tuning knobs (VERDICT r3 #8 moved them out of the product
+    header).  A copy can drift.  This compiles tools/tune_cycle.hip to gfx950 assembly and compares the PRODUCT instantiation
+    modgpu_cycle_queue_kernel<4, 1024> with the lab kernel at the product's settings, opcode by opcode: the same instructions the
+    same number of times, give or take the wait / hazard-nop bookkeeping that moves with the kernel-argument layout.  So an A/B row
+    of tools/tune_cycle against "the lab form" is an A/B against what ships."""
+    import collections
+    hipcc = "/opt/rocm/bin/hipcc"
+    assert os.path.exists(hipcc), "hipcc is missing"
+    tools, csrc = os.path.join(ROOT, "tools"), os.path.join(ROOT, "modulate_amd", "csrc")
+    subprocess.check_call(["make", "-s", "-C", tools, "golden_kat.inc"])
+    flags = subprocess.run(["make", "-s", "-C", csrc, "--eval", "print-kflags: ; @echo $(KERNEL_FLAGS)", "print-kflags"], capture_output=True, text=True).stdout.split()
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-I" + csrc, "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                        os.path.join(tools, "tune_cycle.hip"), "-o", "-"], capture_output=True, text=True, timeout=900, cwd=tools)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = r.stdout
+
+    def histogram(label):
+        m = re.search(r"^(" + label + r"):", asm, re.M)
+        assert m, label
+        h = collections.Counter()
+        for ln in asm[m.end():asm.index("s_endpgm", m.end())].splitlines():
+            ln = ln.strip()
+            if ln and not ln.startswith((";", ".")) and not ln.endswith(":"):
+                h[ln.split()[0]] += 1
+        return h
+    product = histogram(r"_Z25modgpu_cycle_queue_kernelILi4ELi1024EEv14CycleQueueArgs")
+    # <U 4, BLOCK 1024, ALG 2, SAUX sc1|nt, TRACE 0, DEPTH 1, MODE_FULL, LAUX nt, B1 1, B2 1, TSPLIT 0, TK 1, TLOOP 0>
+    lab = histogram(r"_Z22lab_cycle_queue_kernelILi4ELi1024ELi2ELi18ELi0ELi1ELi0ELi2ELi1ELi1ELi0ELi1ELi0EEv12LabQueueArgs")
+    bookkeeping = {"s_waitcnt", "s_nop", "s_mov_b32", "s_mov_b64"}
+    diff = {k: (product[k], lab[k]) for k in set(product) | set(lab) if product[k] != lab[k]}
+    assert all(k in bookkeeping and abs(a - b) <= 4 for k, (a, b) in diff.items()), diff
+    assert product["v_mad_u64_u32"] == lab["v_mad_u64_u32"] > 250 and product["buffer_load_dwordx4"] == lab["buffer_load_dwordx4"] == 13
+    assert product["global_atomic_add"] == lab["global_atomic_add"] == 4 and product["s_barrier"] == lab["s_barrier"]
+
+
 @pytest.mark.parametrize("env,want", [
     ({}, {"pipes": 8, "chunk_bytes": 8 << 20, "zerocopy_max_bytes": 1 << 20, "ring": 4}),
     # ADVICE r1: a zero-copy limit above the slot size used to overrun the pinned staging slot
