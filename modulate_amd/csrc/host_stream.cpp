@@ -112,6 +112,7 @@ const uint64_t kRamp = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_RAMP_KB
 //                           (profiles/r04_staged_midsize.txt: a 512 KiB kernel launched at 20 us returned at 510 us).  Two lanes
 //                           keep the link full across the gap between kernels and still finish chunks in the order they came.
 const int kLanes = env_int("MODGPU_HOST_LANES", 2, 0, 8);
+const int kFileLanes = env_int("MODGPU_HOST_FILE_LANES", 0, 0, 8); // the same for calls with a file on either side (A/B: profiles/r04_file_routes.txt)
 
 // ---- host-side timeline of the staged / pinned routes (modgpu_host_trace, reporting only) --------------------------------
 std::atomic<bool> g_trace_on{false};
@@ -593,7 +594,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     lease.acquire(pipes * ring, ring);
     pipes = (int)lease.ids.size() / ring;
     job.plan = cut_stream(n, chunk, pipes, mem_both ? kRamp : 0);
-    for (int k = 0; mem_both && k < kLanes && k < (int)lease.ids.size(); ++k) job.lanes.push_back(nullptr); // (streams exist after staging_reserve)
+    for (int k = 0; k < (mem_both ? kLanes : kFileLanes) && k < (int)lease.ids.size(); ++k) job.lanes.push_back(nullptr); // (streams exist after staging_reserve)
     trace(MODGPU_TRACE_SLOTS, -1, (uint64_t)pipes, chunk);
     rc = staging_reserve(s, lease.ids, chunk, !job.slot_kernel && !job.in_dst, !(src_direct && dst_direct) && !job.in_dst);
     if (rc) return rc;

@@ -7,6 +7,8 @@ rm -rf $O; mkdir -p $O
 for rep in 1 2 3; do
   MODGPU_HOST_LANES=0 MODGPU_HOST_RAMP_KB=0 MODGPU_HOST_SPLIT=16 MODGPU_HOST_CHUNK_MIN_MB=4 modulate_amd/bin/modbench --files /dev/shm --bytes 411000000 --bytes 4294967296 > $O/r3_$rep.txt
   modulate_amd/bin/modbench --files /dev/shm --bytes 411000000 --bytes 4294967296 > $O/r4_$rep.txt
+  MODGPU_HOST_FILE_LANES=2 modulate_amd/bin/modbench --files /dev/shm --bytes 411000000 --bytes 4294967296 > $O/l2_$rep.txt
+  MODGPU_HOST_FILE_LANES=4 modulate_amd/bin/modbench --files /dev/shm --bytes 411000000 --bytes 4294967296 > $O/l4_$rep.txt
 done
 for tag in r3 r4; do
   echo "== $tag settings, three runs: route GB/s (file->file, file->pinned, pinned->file) at 392 MiB | 4096 MiB"
