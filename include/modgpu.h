@@ -42,7 +42,8 @@
  * that finds too few free takes fewer pipelines; one that finds none waits for a release).  The library keeps parked worker
  * threads (per device for the staging pipelines, one pool for the host loop): started on first use, never joined.
  *
- * Environment (each read once, when first needed):
+ * Environment (each read once, when first needed) -- these ten and no others (tests/test_capi_cpu.py compares this list with the
+ * strings of the built library):
  *     MODGPU_REQUIRE_GPU=1       no host loop anywhere (see above)
  *     MODGPU_MIN_GPU_BYTES=n     modgpu_cycle_auto_host's size threshold (default 16 MiB, the measured crossover
  *                                against one host thread; 0 = always the GPU)
@@ -53,16 +54,15 @@
  *     MODGPU_HOST_ISA=name       host-loop body: generic | avx2 | avx512 (default: the best the CPU runs)
  *     MODGPU_HOST_THREADS=n      most host threads one host-loop call may use (default min(cores, 32); never more than the
  *                                control group's CPU quota or the caller's affinity mask allow)
- *     MODGPU_HOST_SPREAD=1       bind each host-loop worker to a CPU of its own for the length of its span, taken from the CALLING
- *                                thread's affinity mask at every call (default: the scheduler places the parked workers, which is
- *                                faster for this memory-bound loop); the calling thread itself is never re-bound
- *     MODGPU_HOST_CGROUP=0       do not cap the host loop's threads at the control group's CPU quota
+ *     MODGPU_HOST_PIPES=n        pipelines (host threads) one host-buffer call spreads its staging copies over (1..16, default 8)
+ *     MODGPU_HOST_CHUNK_MB=n     largest page-locked staging slot in MiB (1..256, default 8): 2 x pipelines of them per caller at work
  *     MODGPU_DEVICE_ALIAS=n      see modgpu_device_count
- *     MODGPU_HOST_PIPES / _CHUNK_MB / _CHUNK_MIN_MB / _SPLIT / _RAMP_KB / _LANES / _ZEROCOPY_KB / _RING
- *                                staging pipelines of the host-buffer routes (modulate_amd/csrc/host_stream.cpp)
  *     MODGPU_NUMA=0              do not place host memory and worker threads next to their GPU
  *     MODGPU_HELPER_BELOW_MHZ=n  shader clock below which the helper workgroups of a large launch join in (default: 77 % of the
  *                                device's peak shader clock, 1 848 MHz on MI355X; 0 = never)
+ * (How a staged stream is cut and queued -- chunk count, ramp, lanes, copy flavour, ring depth -- and the host loop's binding and
+ * control-group switches were environment variables until ABI 6.  They are constants now, the values the committed profiles
+ * chose; the testing flavour of the library, libmodgpu_testing.so, still has them as knobs: include/modgpu_testing.h.)
  */
 #ifndef MODGPU_H
 #define MODGPU_H
@@ -91,7 +91,7 @@ extern "C" {
 #define MODGPU_KEY_PS4 0x90cfc0abu
 
 /* ABI version of this header (bumped on any signature change). */
-#define MODGPU_ABI_VERSION 6
+#define MODGPU_ABI_VERSION 7
 int modgpu_abi_version(void);
 
 /* Number of HIP devices this library addresses (0 if none / runtime unusable).  Normally the
@@ -152,9 +152,19 @@ int modgpu_cycle_scalar_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_
 /* What CEncryptionCycler::Cycle binds to (`if (n < threshold || !gpu_ok) cpu_loop(); else ...`).
  * n < MODGPU_MIN_GPU_BYTES -- the headers the reference's three call sites pass -- is served by the host loop,
  * which finishes such a buffer before a kernel launch would have returned; larger buffers by modgpu_cycle_host.
- * The reference's Cycle returns void and cannot fail (CEncryptionCycler.cpp:4-14), so when no GPU is visible,
- * or the GPU attempt fails before it has touched host_buf, the host loop finishes the call.  With
- * MODGPU_REQUIRE_GPU=1 there is no second engine: every size runs on the kernel and a GPU error is returned.
+ * The reference's Cycle returns void and cannot fail (CEncryptionCycler.cpp:4-14) and its callers do not guard it
+ * (CArk.cpp:338-339, 1135-1136, Modulate.cpp:485-486), so the host loop finishes the call
+ *   - when no GPU is visible, or the GPU attempt fails before it has changed host_buf: the whole buffer;
+ *   - when the GPU is lost AFTER the call has begun on ordinary (pageable) memory -- what an unmodified caller passes,
+ *     `new char[]` at CArk.cpp:320, 738, 780 -- : the buffer travels in pieces through page-locked slots and a piece changes
+ *     host_buf only when it is copied back whole, so the library knows which pieces have arrived; the other pipelines of the
+ *     call stop at once and the host loop does exactly the pieces that have not (keystream position = stream_off + the
+ *     piece's offset).  modgpu_path_stats().midcall_rescues counts such calls.
+ * ONE case stays an error: page-locked memory (modgpu_host_alloc / _register) is cycled where it lies by one kernel across
+ * PCIe; if that kernel dies under way nobody knows which bytes it had written, and the plaintext exists nowhere else.  The call
+ * then returns MODGPU_ERR_HIP with host_buf in an undefined state.  (A caller that must survive even that keeps its own copy,
+ * or passes pageable memory.)  With MODGPU_REQUIRE_GPU=1 there is no second engine: every size runs on the kernel and a GPU
+ * error is returned.
  * Above the threshold the default policy is to OFFLOAD: on a host with many cores the threaded host loop is faster than one
  * GPU's PCIe link for host-resident data (the link, ~50 GB/s, is the bound), but the kernel leaves those cores to the caller
  * and scales with the number of GPUs; MODGPU_HOST_POLICY=fastest picks the faster engine per call instead. */
@@ -202,7 +212,10 @@ int modgpu_cycle_parts_device(void *const *dev_parts, const uint64_t *sizes, con
  * spelling (compared by device and inode): it is then cycled in place. */
 int modgpu_cycle_file(const char *src_path, const char *dst_path, int32_t key, uint64_t stream_off, int device);
 
-/* n bytes at byte offset file_off of `path` -> host_dst[0..n). */
+/* n bytes at byte offset file_off of `path` -> host_dst[0..n).  If the GPU is lost after the call has begun, the pieces that have
+ * not arrived in host_dst are read from the file again and done by the host loop (the file still holds every byte, whatever
+ * kind of memory host_dst is) -- unless MODGPU_REQUIRE_GPU=1; counted in modgpu_path_stats().midcall_rescues.  Without a
+ * usable GPU at the start the call fails like every other kernel entry point. */
 int modgpu_cycle_file_to_host(const char *path, uint64_t file_off, uint8_t *host_dst, uint64_t n, int32_t key,
                               uint64_t stream_off, int device);
 
@@ -255,6 +268,9 @@ typedef struct modgpu_path_stats {
     uint64_t auto_fallbacks; /* modgpu_cycle_auto_host calls that ended on the host loop because the GPU could not serve them */
     uint64_t auto_small;     /* modgpu_cycle_auto_host calls served by the host loop because n < MODGPU_MIN_GPU_BYTES */
     uint64_t auto_policy_host; /* modgpu_cycle_auto_host calls of n >= MODGPU_MIN_GPU_BYTES that MODGPU_HOST_POLICY=fastest kept on the host loop */
+    uint64_t midcall_rescues;       /* calls (modgpu_cycle_auto_host, modgpu_cycle_file_to_host) whose GPU was lost AFTER the call had begun and
+                                       that the host loop finished: counted in gpu_calls AND -- for _auto_ -- in auto_fallbacks */
+    uint64_t midcall_rescued_bytes; /* bytes of those calls the host loop did (in scalar_bytes, not in gpu_bytes) */
 } modgpu_path_stats_t;
 /* Process-wide counters since load (or the last reset).  reset != 0 zeroes them after the read. */
 int modgpu_path_stats(modgpu_path_stats_t *out, int reset);

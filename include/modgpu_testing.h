@@ -50,7 +50,8 @@ void modgpu_host_tunables(uint64_t out[4]);
 /* ... and the three that shape the chunks of a staged buffer: out[0] = MODGPU_HOST_SPLIT (a buffer is cut into about this many
  * chunks), out[1] = smallest such chunk in bytes (MODGPU_HOST_CHUNK_MIN_MB, never above the largest slot), out[2] = size of each
  * pipeline's first and last chunk in bytes (MODGPU_HOST_RAMP_KB; 0 = no ramp), out[3] = streams a call's kernels across PCIe are
- * queued on in launch order (MODGPU_HOST_LANES; 0 = one stream per slot). */
+ * queued on in launch order (MODGPU_HOST_LANES; 0 = one stream per slot).  In the shipped library these four, the ring depth and
+ * the one-slot limit are constants; the environment names work in the testing flavour only. */
 void modgpu_host_chunking(uint64_t out[4]);
 
 /* Host-side timeline of the host-buffer / file routes: while enabled, every call of modgpu_cycle_host and
@@ -64,11 +65,16 @@ typedef struct modgpu_host_trace_event {
     int kind; /* MODGPU_TRACE_* */
     int pipe;
     uint64_t chunk, bytes;
+    int tid;      /* OS thread id of the recording thread: rocprofv3's kernel trace names the launching thread of every dispatch, so
+                     a LAUNCHED event and its kernel find each other (tools/summarize_pcie_trace.py) */
+    int reserved;
 } modgpu_host_trace_event_t;
 enum {
     MODGPU_TRACE_CALL_BEGIN = 0, MODGPU_TRACE_SLOTS = 1, MODGPU_TRACE_POSTED = 2, MODGPU_TRACE_PIPE_START = 3, MODGPU_TRACE_FILL_BEGIN = 4,
     MODGPU_TRACE_FILL_END = 5, MODGPU_TRACE_LAUNCHED = 6, MODGPU_TRACE_SYNC_BEGIN = 7, MODGPU_TRACE_SYNC_END = 8, MODGPU_TRACE_DRAIN_END = 9,
-    MODGPU_TRACE_PIPE_END = 10, MODGPU_TRACE_CALL_END = 11
+    MODGPU_TRACE_PIPE_END = 10, MODGPU_TRACE_CALL_END = 11,
+    MODGPU_TRACE_FAILED = 12, /* a pipeline met a failure: chunk = the piece, bytes = the stage (MODGPU_STAGE_*) */
+    MODGPU_TRACE_RESCUED = 13 /* the host loop finished the call: chunk = runs of adjacent pieces, bytes = their bytes */
 };
 /* enable != 0 clears the buffer and starts recording (at most 2^20 events are kept); 0 stops. */
 void modgpu_host_trace(int enable);
@@ -131,6 +137,17 @@ void modgpu_debug_set_batch(int mode);
  * even trip counts and ragged ends on buffers of a few MiB. */
 void modgpu_debug_set_launch(int variant, uint32_t grid_cap);
 
+/* The staging knobs that are constants in the shipped library (host_stream.cpp says which and why): this flavour reads them from
+ * the environment at load under their old names (MODGPU_HOST_ZEROCOPY_KB, _RING, _SPLIT, _CHUNK_MIN_MB, _RAMP_KB, _LANES, _NTCOPY)
+ * and changes them here at run time -- not while a host-buffer call is in flight.  modgpu_host_tunables / _chunking report them. */
+enum { MODGPU_TUNABLE_ZEROCOPY_BYTES = 0, MODGPU_TUNABLE_RING = 1, MODGPU_TUNABLE_SPLIT = 2, MODGPU_TUNABLE_CHUNK_MIN_BYTES = 3,
+       MODGPU_TUNABLE_RAMP_BYTES = 4, MODGPU_TUNABLE_LANES = 5, MODGPU_TUNABLE_NTCOPY = 6 };
+void modgpu_debug_set_host_tunable(int which, uint64_t value);
+
+/* Workgroups of a launch that works across PCIe on page-locked host memory (0 = the product's rule).  Measurement only
+ * (tools/sweep_pcie_grid.py). */
+void modgpu_debug_set_pcie_grid(uint32_t cap);
+
 /* How modgpu_cycle_host treats a pinned caller buffer: 0 = library default (= 2), 1 = DMA ring
  * (H2D -> kernel in HBM -> D2H straight from / to the caller's pages), 2 = one kernel over PCIe on
  * the pages themselves.  Both give the same bytes; tools/sweep_pinned.py times them. */
@@ -145,6 +162,20 @@ void modgpu_debug_set_staged_mode(int mode);
  * anything, as if a HIP call had failed at set-up.  Lets the tests drive modgpu_cycle_auto_host's second branch
  * ("a GPU is visible but the attempt failed") on a machine whose GPU works. */
 void modgpu_debug_inject_failures(int count);
+
+/* Failure injection in the MIDDLE of a call: arms one failure -- "the HIP call of `stage` for piece `piece` of the
+ * next host-buffer / file call that has such a piece fails with MODGPU_ERR_HIP" -- which fires once.  Pieces are numbered in
+ * stream order (a call's plan: host_stream.cpp cut_stream; a header-sized or page-locked in-place call is one piece, number 0);
+ * MODGPU_INJECT_PIECE_LAST / _MIDDLE name the last piece and the one at half the plan, and an index beyond the plan means the last.
+ * Stages: FILL = before the piece is copied / read into its slot; LAUNCH = filled, the kernel launch fails; SYNC = the wait for
+ * the piece's kernel fails (what a GPU dying under way looks like); DRAIN = the kernel finished, the failure comes before the
+ * piece is copied back; AFTER_DRAIN = the piece HAS been copied back, then the failure.  stage < 0 disarms. */
+enum { MODGPU_STAGE_FILL = 0, MODGPU_STAGE_LAUNCH = 1, MODGPU_STAGE_SYNC = 2, MODGPU_STAGE_DRAIN = 3, MODGPU_STAGE_AFTER_DRAIN = 4 };
+#define MODGPU_INJECT_PIECE_LAST (-1)
+#define MODGPU_INJECT_PIECE_MIDDLE (-2)
+void modgpu_debug_inject_failure_at(int64_t piece, int stage);
+/* 1 while an armed failure has not fired yet. */
+int modgpu_debug_injection_armed(void);
 
 
 #ifdef __cplusplus

@@ -67,7 +67,7 @@ EXPORTS = {
 class PathStats(ctypes.Structure):
     """modgpu_path_stats_t (include/modgpu.h)."""
     _fields_ = [(k, _u64) for k in ("gpu_calls", "gpu_bytes", "gpu_launches", "scalar_calls", "scalar_bytes",
-                                    "staged_bytes", "direct_bytes", "auto_fallbacks", "auto_small", "auto_policy_host")]
+                                    "staged_bytes", "direct_bytes", "auto_fallbacks", "auto_small", "auto_policy_host", "midcall_rescues", "midcall_rescued_bytes")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -75,11 +75,11 @@ class PathStats(ctypes.Structure):
 
 class HostTraceEvent(ctypes.Structure):
     """modgpu_host_trace_event_t (include/modgpu_testing.h)."""
-    _fields_ = [("t_ns", _u64), ("kind", _int), ("pipe", _int), ("chunk", _u64), ("bytes", _u64)]
+    _fields_ = [("t_ns", _u64), ("kind", _int), ("pipe", _int), ("chunk", _u64), ("bytes", _u64), ("tid", _int), ("reserved", _int)]
 
 
 HOST_TRACE_KINDS = ("call_begin", "slots", "posted", "pipe_start", "fill_begin", "fill_end", "launched", "sync_begin", "sync_end",
-                    "drain_end", "pipe_end", "call_end")
+                    "drain_end", "pipe_end", "call_end", "failed", "rescued")
 
 
 class LaunchInfo(ctypes.Structure):
@@ -113,7 +113,11 @@ DEBUG_EXPORTS = {
     "modgpu_debug_set_queue_ring": (None, [ctypes.c_uint32]),
     "modgpu_debug_set_helpers": (None, [_int]),
     "modgpu_debug_set_batch": (None, [_int]),
+    "modgpu_debug_set_pcie_grid": (None, [ctypes.c_uint32]),
+    "modgpu_debug_set_host_tunable": (None, [_int, _u64]),
     "modgpu_debug_inject_failures": (None, [_int]),
+    "modgpu_debug_inject_failure_at": (None, [ctypes.c_int64, _int]),
+    "modgpu_debug_injection_armed": (_int, []),
 }
 
 
@@ -260,9 +264,35 @@ def debug_set_staged_mode(mode=0):
     _debug_lib().modgpu_debug_set_staged_mode(mode)
 
 
+HOST_TUNABLES = {"zerocopy_bytes": 0, "ring": 1, "split": 2, "chunk_min_bytes": 3, "ramp_bytes": 4, "lanes": 5, "ntcopy": 6}
+
+
+def debug_set_host_tunable(name, value):
+    """Testing flavour: one of HOST_TUNABLES at run time (not while a host-buffer call is in flight)."""
+    _debug_lib().modgpu_debug_set_host_tunable(HOST_TUNABLES[name], int(value))
+
+
+def debug_set_pcie_grid(cap=0):
+    """Measurement hook: workgroups of a launch across PCIe (0 = the product's rule)."""
+    _debug_lib().modgpu_debug_set_pcie_grid(cap)
+
+
 def debug_inject_failures(count):
     """Test hook: the next `count` host-buffer / file calls fail with MODGPU_ERR_HIP before touching anything."""
     _debug_lib().modgpu_debug_inject_failures(count)
+
+
+STAGE_FILL, STAGE_LAUNCH, STAGE_SYNC, STAGE_DRAIN, STAGE_AFTER_DRAIN = range(5)
+INJECT_PIECE_LAST, INJECT_PIECE_MIDDLE = -1, -2
+
+
+def debug_inject_failure_at(piece, stage):
+    """Test hook: the HIP call of `stage` (STAGE_*) for piece `piece` of the next host-buffer / file call fails, once.  stage < 0 disarms."""
+    _debug_lib().modgpu_debug_inject_failure_at(piece, stage)
+
+
+def debug_injection_armed():
+    return bool(_debug_lib().modgpu_debug_injection_armed())
 
 
 def debug_set_helpers(mode=0):
@@ -353,7 +383,7 @@ def host_trace_read():
     n = lib().modgpu_host_trace_read(None, 0)
     buf = (HostTraceEvent * max(n, 1))()
     n = min(lib().modgpu_host_trace_read(buf, n), n)
-    return [{"t_ns": int(e.t_ns), "kind": HOST_TRACE_KINDS[e.kind], "pipe": e.pipe, "chunk": int(e.chunk), "bytes": int(e.bytes)} for e in buf[:n]]
+    return [{"t_ns": int(e.t_ns), "kind": HOST_TRACE_KINDS[e.kind], "pipe": e.pipe, "chunk": int(e.chunk), "bytes": int(e.bytes), "tid": e.tid} for e in buf[:n]]
 
 
 def host_pool_stats():

@@ -15,6 +15,12 @@
 //       when the slots were there, when each pipeline started, and per pipeline what its time went into -- filling slots
 //       (memcpy in), waiting for kernels, draining slots (memcpy out); full event list for the 64 MiB call.  Then two
 //       callers at once on one GPU (64 MiB each) against one caller alone.
+//   modbench --route pinned|staged --mib N [--reps R]
+//       R calls of modgpu_cycle_host over ONE buffer of N MiB -- page-locked (modgpu_host_alloc: cycled in place by one kernel
+//       across PCIe) or pageable (the staged route) -- with the host-side timeline on for the whole run.  Prints every call's wall
+//       time and, one line each, every kernel launch the library made (thread id, call, pipeline, piece, bytes): run under
+//       `rocprofv3 --kernel-trace`, tools/summarize_pcie_trace.py joins those lines with the trace's dispatches by thread id and
+//       order and gives bytes / duration per kernel, the share of the wall clock with a kernel running, and the gaps on each lane.
 //   modbench --alloc
 //       what the part buffer costs: modgpu_host_alloc against modgpu_host_alloc_parts, and the kernel's rate on each.
 //   modbench --numa
@@ -258,7 +264,7 @@ int HostCall()
 int HostTrace()
 {
     if( modgpu_device_count() < 1 ) { std::printf( "no HIP device\n" ); return 1; }
-    static const char* kKind[] = { "call_begin", "slots", "posted", "pipe_start", "fill_begin", "fill_end", "launched", "sync_begin", "sync_end", "drain_end", "pipe_end", "call_end" };
+    static const char* kKind[] = { "call_begin", "slots", "posted", "pipe_start", "fill_begin", "fill_end", "launched", "sync_begin", "sync_end", "drain_end", "pipe_end", "call_end", "failed", "rescued" };
     uint64_t tun[ 4 ], chk[ 4 ];
     modgpu_host_tunables( tun );
     modgpu_host_chunking( chk );
@@ -353,6 +359,64 @@ int HostTrace()
     std::printf( "   staging pool: %llu worker threads started in this process, %llu pipelines run by them, %llu waits for a slot, %llu calls began while another was in flight\n",
                  (unsigned long long)ps[ 0 ], (unsigned long long)ps[ 1 ], (unsigned long long)ps[ 2 ], (unsigned long long)ps[ 3 ] );
     return 0;
+}
+
+// ---- --route: one host-buffer route, R calls, every launch listed (to be joined with a rocprofv3 kernel trace) -------------------
+int Route( const std::string& kind, uint64_t mib, int reps )
+{
+    if( modgpu_device_count() < 1 ) { std::printf( "no HIP device\n" ); return 1; }
+    const uint64_t n = mib << 20;
+    const bool pinned = kind == "pinned";
+    void* mem = nullptr;
+    std::vector< unsigned char > pageable;
+    if( pinned ) TRY( modgpu_host_alloc( &mem, n + 64 ) );
+    else { pageable.assign( n + 64, 0 ); mem = pageable.data(); }
+    unsigned char* buf = static_cast< unsigned char* >( mem ) + 4; // the reference's callers pass buf + 4
+    const std::vector< unsigned char > tile = Tile( 1u << 20, 777 );
+    for( uint64_t off = 0; off < n; off += tile.size() ) std::memcpy( buf + off, tile.data(), std::min< uint64_t >( tile.size(), n - off ) );
+    uint64_t tun[ 4 ], chk[ 4 ];
+    modgpu_host_tunables( tun );
+    modgpu_host_chunking( chk );
+    std::printf( "route %s  bytes %llu  reps %d  pinned_as_seen_by_the_library %d  pipes<=%llu slot<=%lluMiB split~%llu chunk>=%lluMiB ramp %lluKiB lanes %llu\n", kind.c_str(),
+                 (unsigned long long)n, reps, modgpu_host_is_pinned( buf, n ), (unsigned long long)tun[ 0 ], (unsigned long long)( tun[ 1 ] >> 20 ),
+                 (unsigned long long)chk[ 0 ], (unsigned long long)( chk[ 1 ] >> 20 ), (unsigned long long)( chk[ 2 ] >> 10 ), (unsigned long long)chk[ 3 ] );
+    modgpu_host_trace( 1 ); // from the first call on: the launch list below must hold EVERY launch the profiler sees
+    for( int i = 0; i < 2; ++i ) TRY( modgpu_cycle_host( buf, n, kKey, 0, 0 ) ); // slots, workers, page faults
+    std::vector< double > walls;
+    for( int r = 0; r < reps; ++r )
+    {
+        const double t0 = Now();
+        TRY( modgpu_cycle_host( buf, n, kKey, 0, 0 ) );
+        walls.push_back( Now() - t0 );
+    }
+    modgpu_host_trace( 0 );
+    std::vector< double > sorted = walls;
+    std::sort( sorted.begin(), sorted.end() );
+    std::printf( "calls (after 2 untimed): best %.3f ms = %.2f GB/s, median %.3f ms = %.2f GB/s of payload (each byte crosses the link twice)\n", sorted.front() * 1e3,
+                 n / sorted.front() / 1e9, sorted[ sorted.size() / 2 ] * 1e3, n / sorted[ sorted.size() / 2 ] / 1e9 );
+    for( size_t r = 0; r < walls.size(); ++r ) std::printf( "call %zu wall_us %.1f\n", r + 2, walls[ r ] * 1e6 );
+    std::vector< modgpu_host_trace_event_t > ev( (size_t)modgpu_host_trace_read( nullptr, 0 ) );
+    modgpu_host_trace_read( ev.data(), (int)ev.size() );
+    int call = -1;
+    uint64_t z = ev.empty() ? 0 : ev.front().t_ns;
+    for( const auto& e : ev )
+    {
+        if( e.kind == MODGPU_TRACE_CALL_BEGIN ) { ++call; std::printf( "callbegin %d t_us %.1f\n", call, ( e.t_ns - z ) * 1e-3 ); }
+        if( e.kind == MODGPU_TRACE_CALL_END ) std::printf( "callend %d t_us %.1f\n", call, ( e.t_ns - z ) * 1e-3 );
+        if( e.kind == MODGPU_TRACE_LAUNCHED ) std::printf( "launch tid %d call %d pipe %d piece %llu bytes %llu t_us %.1f\n", e.tid, call, e.pipe, (unsigned long long)e.chunk, (unsigned long long)e.bytes, ( e.t_ns - z ) * 1e-3 );
+    }
+    // the last call in full: what happens before its first kernel and after its last
+    static const char* kKind[] = { "call_begin", "slots", "posted", "pipe_start", "fill_begin", "fill_end", "launched", "sync_begin", "sync_end", "drain_end", "pipe_end", "call_end", "failed", "rescued" };
+    size_t lastBegin = 0;
+    for( size_t k = 0; k < ev.size(); ++k ) if( ev[ k ].kind == MODGPU_TRACE_CALL_BEGIN ) lastBegin = k;
+    for( size_t k = lastBegin; k < ev.size(); ++k )
+        std::printf( "event %9.1f %-11s pipe %3d piece %4llu bytes %9llu tid %d\n", ( ev[ k ].t_ns - ev[ lastBegin ].t_ns ) * 1e-3, kKind[ ev[ k ].kind ], ev[ k ].pipe, (unsigned long long)ev[ k ].chunk, (unsigned long long)ev[ k ].bytes, ev[ k ].tid );
+    bool restored = true; // an even number of passes
+    if( ( reps + 2 ) % 2 == 0 )
+        for( uint64_t off = 0; off < n && restored; off += tile.size() ) restored = std::memcmp( buf + off, tile.data(), std::min< uint64_t >( tile.size(), n - off ) ) == 0;
+    std::printf( "even_passes_restore_input %s\n", ( reps + 2 ) % 2 ? "n/a" : ( restored ? "true" : "false" ) );
+    if( pinned ) TRY( modgpu_host_free( mem ) );
+    return restored ? 0 : 2;
 }
 
 // ---- --files: the file routes beside their ceilings ---------------------------------------------------------------------
@@ -579,6 +643,9 @@ int main( int argc, char** argv )
     std::vector< uint64_t > fileSizes;
     std::vector< const char* > positional;
     bool trace = false;
+    std::string route;
+    uint64_t routeMib = 64;
+    int routeReps = 10;
     for( int i = 1; i < argc; ++i )
     {
         const std::string a = argv[ i ];
@@ -590,6 +657,9 @@ int main( int argc, char** argv )
         else if( a == "--warmup" ) warmup = std::atoi( next() );
         else if( a == "--hostcall" ) mode = "hostcall";
         else if( a == "--trace" ) trace = true;
+        else if( a == "--route" ) { mode = "route"; route = next(); }
+        else if( a == "--mib" ) routeMib = std::strtoull( next(), nullptr, 0 );
+        else if( a == "--reps" ) routeReps = std::max( 1, std::atoi( next() ) );
         else if( a == "--alloc" ) { mode = "alloc"; partBytes = 3291444381ull; nParts = 8; }
         else if( a == "--numa" ) { mode = "numa"; partBytes = 1ull << 30; }
         else if( a == "--files" ) { mode = "files"; dir = next(); }
@@ -597,6 +667,7 @@ int main( int argc, char** argv )
         else positional.push_back( argv[ i ] );
     }
     if( mode == "hostcall" ) return trace ? HostTrace() : HostCall();
+    if( mode == "route" ) return route == "pinned" || route == "staged" ? Route( route, routeMib, routeReps ) : 1;
     if( modgpu_device_count() < 1 ) { std::printf( "no HIP device\n" ); return 1; }
     if( mode == "parts" ) return nParts > 0 ? Parts( nParts, devices, partBytes, steps, std::max( warmup, 1 ) ) : 1;
     if( mode == "files" ) return Files( dir, fileSizes );

@@ -31,6 +31,7 @@
 // every step of a call with a timestamp; bin/modbench --hostcall --trace prints the timeline.
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <immintrin.h>
@@ -49,6 +50,7 @@
 
 #include "../../include/modgpu_testing.h"
 #include "modgpu_internal.h"
+#include "scalar_path.h"
 
 namespace modgpu {
 
@@ -58,30 +60,56 @@ namespace modgpu {
 std::atomic<int> g_pinned_mode{0};
 std::atomic<int> g_staged_mode{0};
 std::atomic<int> g_inject_failures{0}; // modgpu_debug_inject_failures
+std::atomic<int64_t> g_inject_piece{0}; // modgpu_debug_inject_failure_at: armed while g_inject_stage >= 0, fires once
+std::atomic<int> g_inject_stage{-1};
 namespace {
 int pinned_mode() { return g_pinned_mode.load(std::memory_order_relaxed); }
 int staged_mode() { return g_staged_mode.load(std::memory_order_relaxed); }
 bool injected_failure() { return g_inject_failures.load(std::memory_order_relaxed) > 0 && g_inject_failures.fetch_sub(1) > 0; }
+// "the HIP call of `stage` for piece `piece` (of `pieces`) fails": true exactly once per arming
+bool injected_at(uint64_t piece, uint64_t pieces, int stage)
+{
+    int armed = g_inject_stage.load(std::memory_order_acquire);
+    if (armed != stage || pieces == 0) return false;
+    const int64_t want = g_inject_piece.load(std::memory_order_relaxed);
+    const uint64_t target = want == MODGPU_INJECT_PIECE_LAST ? pieces - 1 : want == MODGPU_INJECT_PIECE_MIDDLE ? pieces / 2 : std::min<uint64_t>((uint64_t)want, pieces - 1);
+    return piece == target && g_inject_stage.compare_exchange_strong(armed, -1, std::memory_order_acq_rel);
+}
 } // namespace
 #else
 namespace {
 constexpr int pinned_mode() { return 0; }
 constexpr int staged_mode() { return 0; }
 constexpr bool injected_failure() { return false; }
+constexpr bool injected_at(uint64_t, uint64_t, int) { return false; }
 } // namespace
 #endif
 
 namespace {
 
 constexpr int kMaxPipes = 16;
-constexpr int kSlots = 32; // pipes x ring depth: 16 x 2 (staged) or up to 8 x 4 (direct)
+constexpr int kSlots = 34;     // pipes x ring depth: 16 x 2 (staged) or up to 8 x 4 (direct) ...
+constexpr int kPipeSlots = 32; // ... + 2 that only one-slot calls may take: a 4 KiB header Cycle never waits for a multi-GiB call to end
 
-// Tunables, read once at load:
-//   MODGPU_HOST_PIPES       host threads / independent pipelines for large pageable buffers (1..16)
-//   MODGPU_HOST_CHUNK_MB    largest slot in MiB (1..256)
-//   MODGPU_HOST_ZEROCOPY_KB largest buffer cycled in place in pinned memory by the kernel (0 = never);
-//                           never larger than a slot, whatever the two variables say
-//   MODGPU_HOST_RING        device slots in flight on the pinned (DMA) route (2..4)
+// ---- how a stream is cut and queued ------------------------------------------------------------------------------------------
+// The shipped library reads TWO of these from the environment, once, at load:
+//   MODGPU_HOST_PIPES       host threads / independent pipelines for large pageable buffers (1..16; default 8)
+//   MODGPU_HOST_CHUNK_MB    largest slot in MiB (1..256; default 8)
+// Everything else is a constant there -- the values the profiles named below chose -- and a knob only in the TESTING flavour
+// (libmodgpu_testing.so: the same names in the environment at load, and modgpu_debug_set_host_tunable at run time), so that the
+// parity suite can still drive every branch and tools/ can still sweep, but a production process has ten documented variables,
+// not twenty:
+//   zero_copy_max  largest buffer cycled in one pinned slot by one kernel, no chunking (1 MiB; never larger than a slot)
+//   ring           device slots in flight on the DMA form of the pinned route (4)
+//   split          a buffer is cut into about this many chunks ...                                   (16)
+//   chunk_min      ... of at least this many bytes (and at most a slot)                               (2 MiB)
+//   ramp           each pipeline's FIRST and LAST chunk are this small (0 = all alike): nothing crosses the link while the first
+//                  chunks are being copied in, nor while the last ones are copied out                 (1 MiB)
+//   lanes          streams a call's kernels-across-PCIe are queued on, in launch order, round robin (0 = every slot its own
+//                  stream, the round-3 form: the GPU then runs all 16 chunk kernels of a call at once, each on a sixteenth of the
+//                  link, and they all finish late together, profiles/r04_staged_midsize.txt)           (4 since round 5)
+//   nt_copy        the staging copies use non-temporal stores (1)
+// Chunking defaults: profiles/r04_staged_midsize.txt (16 ... 256 MiB, pageable, settings interleaved); lanes: profiles/r05_pcie_grid.txt.
 int env_int(const char *name, int dflt, int lo, int hi)
 {
     const char *v = std::getenv(name);
@@ -89,30 +117,23 @@ int env_int(const char *name, int dflt, int lo, int hi)
     int x = std::atoi(v);
     return x < lo ? lo : (x > hi ? hi : x);
 }
+#ifdef MODGPU_TESTING_HOOKS
+#define MODGPU_KNOB(name, dflt, lo, hi) env_int(name, dflt, lo, hi)
+#define MODGPU_KNOB_STORAGE // (changed between calls by modgpu_debug_set_host_tunable)
+#else
+#define MODGPU_KNOB(name, dflt, lo, hi) (dflt)
+#define MODGPU_KNOB_STORAGE const
+#endif
 const int kPipes = env_int("MODGPU_HOST_PIPES", 8, 1, kMaxPipes);
 const uint64_t kChunk = (uint64_t)env_int("MODGPU_HOST_CHUNK_MB", 8, 1, 256) << 20;
-const uint64_t kZeroCopyMax = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_ZEROCOPY_KB", 1024, 0, 1 << 20) << 10, kChunk);
-const int kRing = env_int("MODGPU_HOST_RING", 4, 2, 4);
-//   MODGPU_HOST_SPLIT       a buffer is cut into about this many slots' worth of chunks ...
-//   MODGPU_HOST_CHUNK_MIN_MB  ... of at least this many MiB (and at most MODGPU_HOST_CHUNK_MB)
-//   MODGPU_HOST_RAMP_KB     each pipeline's FIRST and LAST chunk are this small (0 = all chunks alike): nothing crosses the link
-//                           while the first chunks are being copied in, nor while the last ones are copied out
-// Defaults from profiles/r04_staged_midsize.txt (16 ... 256 MiB, pageable, settings interleaved, best of 18 calls each): ~16 chunks of
-// >= 2 MiB behind a 1 MiB ramp, two lanes and non-temporal copies are at or within 4 % of the best row at every size (round 3: ~16
-// chunks of >= 4 MiB, no ramp, a stream per slot, memcpy); the timelines there show why the ramp, the lanes and the copies exist.
-// (Before the copies were fast, finer chunks -- ~32 of >= 1 MiB -- measured best; with them a chunk's kernel is the longer stage, and
-// a kernel of 2-4 MiB uses the link better than one of 1 MiB.)
-const uint64_t kSplit = (uint64_t)env_int("MODGPU_HOST_SPLIT", 16, 2, 256);
-const uint64_t kChunkMin = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_CHUNK_MIN_MB", 2, 1, 256) << 20, kChunk);
-const uint64_t kRamp = std::min<uint64_t>((uint64_t)env_int("MODGPU_HOST_RAMP_KB", 1024, 0, 1 << 18) << 10, kChunk);
-//   MODGPU_HOST_LANES       streams a call's kernels-across-PCIe are queued on, in launch order, round robin (0 = every slot its
-//                           own stream, the round-3 form).  With a stream per slot the GPU runs all 16 chunk kernels of a call at
-//                           once, each on a sixteenth of the link, and they all finish late together -- the first chunk's bytes
-//                           come back when the last chunk's do, and nothing can be copied out meanwhile
-//                           (profiles/r04_staged_midsize.txt: a 512 KiB kernel launched at 20 us returned at 510 us).  Two lanes
-//                           keep the link full across the gap between kernels and still finish chunks in the order they came.
-const int kLanes = env_int("MODGPU_HOST_LANES", 2, 0, 8);
-const int kFileLanes = env_int("MODGPU_HOST_FILE_LANES", 0, 0, 8); // the same for calls with a file on either side (A/B: profiles/r04_file_routes.txt)
+MODGPU_KNOB_STORAGE uint64_t kZeroCopyMax = std::min<uint64_t>((uint64_t)MODGPU_KNOB("MODGPU_HOST_ZEROCOPY_KB", 1024, 0, 1 << 20) << 10, kChunk);
+MODGPU_KNOB_STORAGE int kRing = MODGPU_KNOB("MODGPU_HOST_RING", 4, 2, 4);
+MODGPU_KNOB_STORAGE uint64_t kSplit = (uint64_t)MODGPU_KNOB("MODGPU_HOST_SPLIT", 16, 2, 256);
+MODGPU_KNOB_STORAGE uint64_t kChunkMin = std::min<uint64_t>((uint64_t)MODGPU_KNOB("MODGPU_HOST_CHUNK_MIN_MB", 2, 1, 256) << 20, kChunk);
+MODGPU_KNOB_STORAGE uint64_t kRamp = std::min<uint64_t>((uint64_t)MODGPU_KNOB("MODGPU_HOST_RAMP_KB", 1024, 0, 1 << 18) << 10, kChunk);
+MODGPU_KNOB_STORAGE int kLanes = MODGPU_KNOB("MODGPU_HOST_LANES", 4, 0, 8);
+MODGPU_KNOB_STORAGE bool kNtCopy = MODGPU_KNOB("MODGPU_HOST_NTCOPY", 1, 0, 1) != 0;
+constexpr int kFileLanes = 0; // calls with a file on either side keep a stream per slot: lanes made no difference there (profiles/r04_file_routes.txt)
 
 // ---- host-side timeline of the staged / pinned routes (modgpu_host_trace, reporting only) --------------------------------
 std::atomic<bool> g_trace_on{false};
@@ -124,7 +145,8 @@ inline void trace(int kind, int pipe, uint64_t chunk, uint64_t bytes)
     std::lock_guard<std::mutex> lock(g_trace_mu);
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts); // (read under the lock: the log is in time order)
-    if (g_trace.size() < (1u << 20)) g_trace.push_back({(uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec, kind, pipe, chunk, bytes});
+    static thread_local const int tid = (int)::syscall(SYS_gettid); // (what rocprofv3's kernel trace calls Thread_Id)
+    if (g_trace.size() < (1u << 20)) g_trace.push_back({(uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec, kind, pipe, chunk, bytes, tid, 0});
 }
 
 struct Call;
@@ -155,13 +177,17 @@ struct SlotLease {
     explicit SlotLease(Staging &st) : s(st) {}
     SlotLease(const SlotLease &) = delete;
     SlotLease &operator=(const SlotLease &) = delete;
-    // takes up to `want` slots in whole groups of `group`; waits while fewer than one group is free
+    // takes up to `want` slots in whole groups of `group`; waits while fewer than one group is free.  A call that asks for ONE
+    // slot (header-sized buffers, page-locked memory cycled in place) may take any, the last two first; every other call only the
+    // first kPipeSlots -- so the one-slot routes find a slot however many large calls are at work.
     void acquire(int want, int group)
     {
         std::unique_lock<std::mutex> lock(s.mu);
+        const bool single = want == 1 && group == 1;
+        const int limit = single ? kSlots : kPipeSlots;
         auto n_free = [&] {
             int f = 0;
-            for (int i = 0; i < kSlots; ++i) f += s.busy[i] ? 0 : 1;
+            for (int i = 0; i < limit; ++i) f += s.busy[i] ? 0 : 1;
             return f;
         };
         if (n_free() < group) {
@@ -169,11 +195,13 @@ struct SlotLease {
             s.slot_cv.wait(lock, [&] { return n_free() >= group; });
         }
         const int take = std::min(want, n_free()) / group * group;
-        for (int i = 0; i < kSlots && (int)ids.size() < take; ++i)
+        for (int k = 0; k < limit && (int)ids.size() < take; ++k) {
+            const int i = single ? limit - 1 - k : k;
             if (!s.busy[i]) {
                 s.busy[i] = true;
                 ids.push_back(i);
             }
+        }
     }
     ~SlotLease()
     {
@@ -217,8 +245,7 @@ int staging_reserve(Staging &s, const std::vector<int> &ids, uint64_t need, bool
 // thread, because both are DRAM-miss streams -- and a plain memcpy of a few MiB also READS every destination line before it
 // overwrites it (write-allocate).  A copy with non-temporal stores does not: two DRAM streams instead of three.  The bytes are
 // not wanted in this core's cache anyway -- the slot is read next by the GPU across PCIe, the caller's buffer by whoever comes next.
-// MODGPU_HOST_NTCOPY=0 falls back to memcpy (read once).
-const bool kNtCopy = env_int("MODGPU_HOST_NTCOPY", 1, 0, 1) != 0;
+// (nt_copy = 0, testing flavour: plain memcpy.)
 __attribute__((target("avx2"))) void copy_nt_avx2(uint8_t *dst, const uint8_t *src, uint64_t n)
 {
     // head: up to the first 32-byte boundary of dst
@@ -276,7 +303,9 @@ int drain_slot(const Endpoint &dst, const uint8_t *pinned, uint64_t off, uint64_
     return MODGPU_OK;
 }
 
-struct Piece { uint64_t off, len; };
+// What a call knows about each piece of its stream.  The cipher is positional and the pieces are disjoint, so a call that loses
+// its GPU half-way can be FINISHED by the host loop over exactly the pieces whose result has not reached the destination
+// (the reference's Cycle cannot fail, CEncryptionCycler.cpp:4-14, and its callers do not guard it).
 struct Job {
     const Endpoint &src, &dst;
     uint64_t n, chunk; // chunk: the largest piece (slot size)
@@ -285,10 +314,19 @@ struct Job {
     bool slot_kernel = false; // staged chunks are cycled in their pinned slot across PCIe (no DMA, no device slot)
     bool in_dst = false;      // file -> page-locked caller memory: pread lands in the destination itself, which the kernel then
                               // cycles where it lies across PCIe (no slot, no DMA, no copy)
-    std::atomic<bool> touched{false};
-    std::vector<Piece> plan; // the stream cut into pieces, in stream order; piece k belongs to pipeline k mod pipes
+    std::atomic<bool> touched{false}; // the destination may differ from what it was
+    std::atomic<bool> failed{false};  // a pipeline failed: the others stop filling and launching at once
+    std::vector<Piece> plan;          // the stream cut into pieces, in stream order; piece k belongs to pipeline k mod pipes
+    std::unique_ptr<std::atomic<uint8_t>[]> done; // per piece: its result is in the destination, whole
     std::vector<hipStream_t> lanes; // kernels across PCIe are queued on these in launch order (empty: each on its slot's stream)
     std::atomic<uint64_t> launched{0};
+    Job(const Endpoint &s, const Endpoint &d, uint64_t n_, uint64_t chunk_, int32_t key_, uint64_t off_) : src(s), dst(d), n(n_), chunk(chunk_), key(key_), stream_off(off_) {}
+    void set_plan(std::vector<Piece> p)
+    {
+        plan = std::move(p);
+        done.reset(new std::atomic<uint8_t>[plan.size() ? plan.size() : 1]);
+        for (size_t k = 0; k < plan.size(); ++k) done[k].store(0, std::memory_order_relaxed);
+    }
 };
 
 // Cuts [0, n) into pieces of `chunk` bytes for `pipes` pipelines.  With a ramp the first and the last `pipes` pieces -- every
@@ -309,8 +347,13 @@ std::vector<Piece> cut_stream(uint64_t n, uint64_t chunk, int pipes, uint64_t ra
     return plan;
 }
 
+constexpr int kStopped = -1000; // run_pipe: another pipeline of the call failed and this one stopped early -- not an error of its own
+
 // One pipeline: chunks first, first+stride, ... of the stream through the `ring` slots slots[0..ring).
 // A pinned memory endpoint is DMA'd directly; anything else passes through the slot's pinned buffer.
+// Failure: the pipeline that meets it raises j.failed, every pipeline sees that at its next step and stops; each waits for what
+// it has in flight and returns.  Pieces whose result had reached the destination are marked in j.done; nothing else of the
+// destination has been written by this route unless j.touched says so (see stream_impl for what that means per route).
 int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uint64_t stride)
 {
     const int pipe = (int)first;
@@ -330,33 +373,48 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
         if (rc == MODGPU_OK && on_lanes) HIP_TRY(hipEventRecord(s.event[slot], st));
         return rc;
     };
+#define MODGPU_INJECT(piece, stage)                                                                                              \
+    do {                                                                                                                         \
+        if (injected_at((piece), n_chunks, (stage))) {                                                                           \
+            trace(MODGPU_TRACE_FAILED, pipe, (piece), (uint64_t)(stage));                                                        \
+            return fail(MODGPU_ERR_HIP, "injected failure (modgpu_debug_inject_failure_at)");                                    \
+        }                                                                                                                        \
+    } while (0)
     auto step = [&](uint64_t i) -> int {
         const int slot = slots[i % (uint64_t)ring];
+        if (j.failed.load(std::memory_order_acquire)) return kStopped;
         if (i >= (uint64_t)ring) { // retire the chunk that used this slot `ring` trips ago
             uint64_t off, len;
             const uint64_t c = first + (i - ring) * stride;
             span(c, &off, &len);
             trace(MODGPU_TRACE_SYNC_BEGIN, pipe, c, len);
+            MODGPU_INJECT(c, MODGPU_STAGE_SYNC);
             if (on_lanes) HIP_TRY(hipEventSynchronize(s.event[slot]));
             else HIP_TRY(hipStreamSynchronize(s.stream[slot]));
             trace(MODGPU_TRACE_SYNC_END, pipe, c, len);
             if (!dst_direct && !j.in_dst) {
+                MODGPU_INJECT(c, MODGPU_STAGE_DRAIN);
                 j.touched.store(true, std::memory_order_relaxed);
                 int rc = drain_slot(j.dst, s.pinned[slot], off, len);
                 trace(MODGPU_TRACE_DRAIN_END, pipe, c, len);
                 if (rc) return rc;
             }
+            j.done[c].store(1, std::memory_order_release); // (a destination written directly -- DMA, or the kernel in place -- holds the piece once the wait has succeeded)
+            MODGPU_INJECT(c, MODGPU_STAGE_AFTER_DRAIN);
+            if (j.failed.load(std::memory_order_acquire)) return kStopped;
         }
         if (i < mine) {
             uint64_t off, len;
             const uint64_t c = first + i * stride;
             span(c, &off, &len);
             trace(MODGPU_TRACE_FILL_BEGIN, pipe, c, len);
+            MODGPU_INJECT(c, MODGPU_STAGE_FILL);
             if (j.in_dst) {
                 j.touched.store(true, std::memory_order_relaxed);
                 int rc = fill_slot(j.src, j.dst.mem + off, off, len);
                 if (rc) return rc;
                 trace(MODGPU_TRACE_FILL_END, pipe, c, len);
+                MODGPU_INJECT(c, MODGPU_STAGE_LAUNCH);
                 void *mapped = nullptr;
                 HIP_TRY(hipHostGetDevicePointer(&mapped, j.dst.mem + off, 0));
                 rc = launch_across_pcie(mapped, len, off, slot);
@@ -367,6 +425,7 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
                 int rc = fill_slot(j.src, s.pinned[slot], off, len);
                 if (rc) return rc;
                 trace(MODGPU_TRACE_FILL_END, pipe, c, len);
+                MODGPU_INJECT(c, MODGPU_STAGE_LAUNCH);
                 void *mapped = nullptr;
                 HIP_TRY(hipHostGetDevicePointer(&mapped, s.pinned[slot], 0));
                 rc = launch_across_pcie(mapped, len, off, slot);
@@ -381,6 +440,7 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
                 HIP_TRY(hipMemcpyAsync(s.dev[slot], s.pinned[slot], len, hipMemcpyHostToDevice, s.stream[slot]));
             }
             trace(MODGPU_TRACE_FILL_END, pipe, c, len);
+            MODGPU_INJECT(c, MODGPU_STAGE_LAUNCH);
             int rc = cycle_device_impl(s.dev[slot], len, j.key, j.stream_off + off, s.stream[slot]);
             if (rc) return rc;
             trace(MODGPU_TRACE_LAUNCHED, pipe, c, len);
@@ -393,9 +453,11 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
         }
         return MODGPU_OK;
     };
+#undef MODGPU_INJECT
     int rc = MODGPU_OK;
     for (uint64_t i = 0; i < mine + (uint64_t)ring && rc == MODGPU_OK; ++i) rc = step(i);
-    if (rc != MODGPU_OK) { // nothing of this call may still be running against the caller's memory once we return
+    if (rc != MODGPU_OK) { // nothing of this call may still be running against the caller's memory (or its slots) once we return
+        if (rc != kStopped) j.failed.store(true, std::memory_order_release);
         const std::string keep = t_err;
         for (int k = 0; k < ring; ++k) (void)hipStreamSynchronize(s.stream[slots[k]]);
         for (hipStream_t st : j.lanes) (void)hipStreamSynchronize(st);
@@ -426,7 +488,8 @@ struct Call {
             const int p = next.fetch_add(1, std::memory_order_relaxed);
             if (p >= pipes) return;
             if (worker) g_pool_tasks.fetch_add(1, std::memory_order_relaxed);
-            rcs[(size_t)p] = run_pipe(s, &slots[(size_t)p * (size_t)ring], ring, job, (uint64_t)p, (uint64_t)pipes);
+            const int rc = run_pipe(s, &slots[(size_t)p * (size_t)ring], ring, job, (uint64_t)p, (uint64_t)pipes);
+            rcs[(size_t)p] = rc == kStopped ? MODGPU_OK : rc; // (stopped because a sibling failed: that one carries the error)
             if (rcs[(size_t)p]) errs[(size_t)p] = t_err;
             std::lock_guard<std::mutex> lock(mu);
             if (++finished == pipes) cv.notify_all();
@@ -482,10 +545,52 @@ void post_to_workers(Staging &s, const std::shared_ptr<Call> &call, int extra, i
 
 } // namespace
 
-int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t key, uint64_t stream_off, int device,
-                bool *touched)
+namespace {
+// The host loop over the pieces of a lost call whose result has not reached the destination (adjacent ones as one run, so that
+// the loop's threads see large spans).  A piece's source bytes are read again where the destination does not still hold them.
+int finish_on_host(const Job &j, uint64_t *bytes_done)
 {
-    if (touched) *touched = false;
+    const bool in_place = j.src.mem && j.src.mem == j.dst.mem;
+    const bool identity = (int64_t)j.key % 0x7FFFFFFFll == 0;
+    std::vector<Piece> runs;
+    for (size_t k = 0; k < j.plan.size(); ++k) {
+        if (j.done[k].load(std::memory_order_acquire)) continue;
+        if (!runs.empty() && runs.back().off + runs.back().len == j.plan[k].off) runs.back().len += j.plan[k].len;
+        else runs.push_back(j.plan[k]);
+    }
+    std::vector<uint8_t> tmp;
+    for (const Piece &r : runs) {
+        if (j.dst.mem) {
+            uint8_t *at = j.dst.mem + r.off;
+            if (!in_place) { // a file, or other memory: the piece's plaintext comes from there again
+                int rc = fill_slot(j.src, at, r.off, r.len);
+                if (rc) return rc;
+            }
+            if (!identity) modgpu_scalar_cycle(at, r.len, j.key, j.stream_off + r.off);
+        } else { // the destination is a file: through a bounce buffer, a slot's worth at a time
+            tmp.resize((size_t)std::min<uint64_t>(r.len, kChunk));
+            for (uint64_t o = 0; o < r.len; o += tmp.size()) {
+                const uint64_t l = std::min<uint64_t>(tmp.size(), r.len - o);
+                int rc = fill_slot(j.src, tmp.data(), r.off + o, l);
+                if (rc) return rc;
+                if (!identity) modgpu_scalar_cycle(tmp.data(), l, j.key, j.stream_off + r.off + o);
+                rc = drain_slot(j.dst, tmp.data(), r.off + o, l);
+                if (rc) return rc;
+            }
+        }
+        *bytes_done += r.len;
+    }
+    trace(MODGPU_TRACE_RESCUED, -1, runs.size(), *bytes_done);
+    return MODGPU_OK;
+}
+} // namespace
+
+int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t key, uint64_t stream_off, int device,
+                bool host_may_finish, StreamOutcome *out)
+{
+    StreamOutcome dummy;
+    StreamOutcome &outcome = out ? *out : dummy;
+    outcome = StreamOutcome{};
     if (n == 0) return MODGPU_OK;
     // byte j is at stream position stream_off + j, taken in the integers and reduced mod the generator's period: reduce the
     // offset first, so that adding a chunk's position below can never wrap at 2^64 (which is not a multiple of the period)
@@ -530,11 +635,19 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
         if (rc) return rc;
         void *mapped = nullptr;
         HIP_TRY(hipHostGetDevicePointer(&mapped, src.mem, 0));
+        if (injected_at(0, 1, MODGPU_STAGE_FILL) || injected_at(0, 1, MODGPU_STAGE_LAUNCH)) return fail(MODGPU_ERR_HIP, "injected failure (modgpu_debug_inject_failure_at)");
         rc = cycle_device_impl(mapped, n, key, stream_off, s.stream[slot], /*over_pcie=*/true);
         if (rc) return rc; // nothing was launched: the caller's pages are as they were
-        if (touched) *touched = true;
-        hipError_t e = hipStreamSynchronize(s.stream[slot]);
-        if (e != hipSuccess) return fail_hip(e, "hipStreamSynchronize (kernel over PCIe)");
+        trace(MODGPU_TRACE_LAUNCHED, -1, 0, n);
+        // From here on the kernel writes the caller's pages itself.  If the wait for it fails nobody knows which of them it
+        // reached before it died, and the plaintext exists nowhere else: THIS route cannot be finished by the host loop, the error
+        // stands (include/modgpu.h says so at modgpu_cycle_auto_host).
+        outcome.touched = true;
+        hipError_t e = injected_at(0, 1, MODGPU_STAGE_SYNC) ? hipErrorLaunchFailure : hipStreamSynchronize(s.stream[slot]);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(s.stream[slot]);
+            return fail_hip(e, "hipStreamSynchronize (kernel over PCIe on the caller's page-locked memory)");
+        }
         account();
         return MODGPU_OK;
     }
@@ -547,12 +660,15 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
         if (s.pinned_cap[slot] < n) return fail(MODGPU_ERR_INVALID, "staging slot smaller than the zero-copy buffer");
         void *mapped = nullptr;
         HIP_TRY(hipHostGetDevicePointer(&mapped, s.pinned[slot], 0));
+        if (injected_at(0, 1, MODGPU_STAGE_FILL)) return fail(MODGPU_ERR_HIP, "injected failure (modgpu_debug_inject_failure_at)");
         std::memcpy(s.pinned[slot], src.mem, n);
-        rc = cycle_device_impl(mapped, n, key, stream_off, s.stream[slot], /*over_pcie=*/true);
+        rc = injected_at(0, 1, MODGPU_STAGE_LAUNCH) ? fail(MODGPU_ERR_HIP, "injected failure (modgpu_debug_inject_failure_at)")
+                                                     : cycle_device_impl(mapped, n, key, stream_off, s.stream[slot], /*over_pcie=*/true);
         hipError_t e = hipStreamSynchronize(s.stream[slot]);
         if (rc) return rc;
-        if (e != hipSuccess) return fail_hip(e, "hipStreamSynchronize (kernel over PCIe)");
-        if (touched) *touched = true;
+        if (e == hipSuccess && (injected_at(0, 1, MODGPU_STAGE_SYNC) || injected_at(0, 1, MODGPU_STAGE_DRAIN))) e = hipErrorLaunchFailure;
+        if (e != hipSuccess) return fail_hip(e, "hipStreamSynchronize (kernel over PCIe)"); // the caller's buffer is as it was: the slot took the damage
+        outcome.touched = true;
         std::memcpy(dst.mem, s.pinned[slot], n);
         account();
         return MODGPU_OK;
@@ -570,7 +686,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
                                     : std::min<uint64_t>(kChunk, std::max<uint64_t>(chunk_min, ((n / split) + 0xFFFFF) & ~0xFFFFFull));
     chunk = std::min<uint64_t>(chunk, kChunk);
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
-    Job job{src, dst, n, chunk, key, stream_off, false, false, {}, {}, {}, {}};
+    Job job(src, dst, n, chunk, key, stream_off);
     // Default routes (profiles/r03_file_routes.txt): pageable memory and files are copied / read into a pinned slot and
     // cycled there across PCIe; a file that ends in page-locked caller memory is read straight into that memory and cycled
     // where it lies; page-locked caller memory that ends in a file is DMA'd.  (Testing flavour, staged mode 1: the DMA
@@ -593,7 +709,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     SlotLease lease(s);
     lease.acquire(pipes * ring, ring);
     pipes = (int)lease.ids.size() / ring;
-    job.plan = cut_stream(n, chunk, pipes, mem_both ? kRamp : 0);
+    job.set_plan(cut_stream(n, chunk, pipes, mem_both ? kRamp : 0));
     for (int k = 0; k < (mem_both ? kLanes : kFileLanes) && k < (int)lease.ids.size(); ++k) job.lanes.push_back(nullptr); // (streams exist after staging_reserve)
     trace(MODGPU_TRACE_SLOTS, -1, (uint64_t)pipes, chunk);
     rc = staging_reserve(s, lease.ids, chunk, !job.slot_kernel && !job.in_dst, !(src_direct && dst_direct) && !job.in_dst);
@@ -602,6 +718,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
 
     if (pipes <= 1) {
         rc = run_pipe(s, lease.ids.data(), ring, job, 0, 1);
+        if (rc == kStopped) rc = MODGPU_OK;
     } else {
         auto call = std::make_shared<Call>(s, job, pipes, ring, physical_of(dev), lease.ids);
         post_to_workers(s, call, pipes - 1, dev);
@@ -614,9 +731,34 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
                 rc = call->rcs[(size_t)p];
             }
     }
-    if (touched) *touched = job.touched.load();
-    if (rc == MODGPU_OK) account();
-    return rc;
+    outcome.touched = job.touched.load();
+    if (rc == MODGPU_OK) {
+        account();
+        return rc;
+    }
+    // ---- the GPU was lost after the call had begun.  Every pipeline has stopped and waited for what it had in flight.
+    // A piece is either marked done -- its result is in the destination, whole -- or not, and then the host loop can still do it
+    // as long as its plaintext is still somewhere: in the source file, in the caller's other buffer, or in the destination itself
+    // when that is only ever written by a finished piece's copy out of its slot (the staged route).  In place AND written
+    // directly by the device (page-locked memory in DMA mode) the plaintext of an unfinished piece is gone: the error stands.
+    const bool dst_written_by_device = dst_direct || job.in_dst;
+    const bool recoverable = rc == MODGPU_ERR_HIP && !(in_place && dst_written_by_device);
+    if (!host_may_finish || !recoverable) return rc;
+    const std::string why = t_err;
+    uint64_t host_bytes = 0;
+    const int rc2 = finish_on_host(job, &host_bytes);
+    if (rc2 != MODGPU_OK) return rc2; // (an I/O error of the rescue itself: its own text)
+    outcome.finished_on_host = true;
+    outcome.host_bytes = host_bytes;
+    outcome.touched = true;
+    g_stats.gpu_calls.fetch_add(1, std::memory_order_relaxed);
+    g_stats.gpu_bytes.fetch_add(n - host_bytes, std::memory_order_relaxed);
+    (all_direct ? g_stats.direct_bytes : g_stats.staged_bytes).fetch_add(n - host_bytes, std::memory_order_relaxed);
+    g_stats.midcall_rescues.fetch_add(1, std::memory_order_relaxed);
+    g_stats.midcall_rescued_bytes.fetch_add(host_bytes, std::memory_order_relaxed);
+    g_stats.scalar_bytes.fetch_add(host_bytes, std::memory_order_relaxed);
+    t_err = "finished on the host loop after: " + why;
+    return MODGPU_OK;
 }
 
 } // namespace modgpu
@@ -635,6 +777,28 @@ extern "C" {
 
 #ifdef MODGPU_TESTING_HOOKS
 void modgpu_debug_inject_failures(int count) { g_inject_failures.store(count > 0 ? count : 0); }
+void modgpu_debug_inject_failure_at(int64_t piece, int stage)
+{
+    g_inject_stage.store(-1, std::memory_order_release);
+    g_inject_piece.store(piece, std::memory_order_relaxed);
+    g_inject_stage.store(stage >= MODGPU_STAGE_FILL && stage <= MODGPU_STAGE_AFTER_DRAIN ? stage : -1, std::memory_order_release);
+}
+int modgpu_debug_injection_armed(void) { return g_inject_stage.load(std::memory_order_acquire) >= 0 ? 1 : 0; }
+// Run-time form of the testing flavour's knobs; not while a host-buffer call is in flight.  Values are clamped like the environment's.
+void modgpu_debug_set_host_tunable(int which, uint64_t value)
+{
+    auto clamp = [](uint64_t v, uint64_t lo, uint64_t hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    switch (which) {
+    case MODGPU_TUNABLE_ZEROCOPY_BYTES: kZeroCopyMax = std::min<uint64_t>(value, kChunk); break;
+    case MODGPU_TUNABLE_RING: kRing = (int)clamp(value, 2, 4); break;
+    case MODGPU_TUNABLE_SPLIT: kSplit = clamp(value, 2, 256); break;
+    case MODGPU_TUNABLE_CHUNK_MIN_BYTES: kChunkMin = std::min<uint64_t>(clamp(value, 1ull << 20, 256ull << 20), kChunk); break;
+    case MODGPU_TUNABLE_RAMP_BYTES: kRamp = std::min<uint64_t>(value, kChunk); break;
+    case MODGPU_TUNABLE_LANES: kLanes = (int)clamp(value, 0, 8); break;
+    case MODGPU_TUNABLE_NTCOPY: kNtCopy = value != 0; break;
+    default: break;
+    }
+}
 #endif
 
 void modgpu_host_trace(int enable)
@@ -699,7 +863,7 @@ int modgpu_cycle_file(const char *src_path, const char *dst_path, int32_t key, u
         Endpoint src, dst;
         src.fd = in_place ? out.fd : in.fd;
         dst.fd = out.fd;
-        return stream_impl(src, dst, (uint64_t)st_in.st_size, key, stream_off, device, nullptr);
+        return stream_impl(src, dst, (uint64_t)st_in.st_size, key, stream_off, device, false, nullptr);
     });
 }
 
@@ -716,7 +880,9 @@ int modgpu_cycle_file_to_host(const char *path, uint64_t file_off, uint8_t *host
         src.base = file_off;
         dst.mem = host_dst;
         dst.pinned = host_range_pinned(host_dst, n);
-        return stream_impl(src, dst, n, key, stream_off, device, nullptr);
+        // The file still holds every byte: if the GPU is lost after the call has begun, the pieces that have not arrived are
+        // read again and done by the host loop (unless MODGPU_REQUIRE_GPU=1) -- LoadArkData's part cipher keeps going.
+        return stream_impl(src, dst, n, key, stream_off, device, !gpu_required(), nullptr);
     });
 }
 
@@ -732,7 +898,7 @@ int modgpu_cycle_host_to_file(const uint8_t *host_src, uint64_t n, const char *p
         src.mem = const_cast<uint8_t *>(host_src); // only read from
         src.pinned = host_range_pinned(host_src, n);
         dst.fd = out.fd;
-        return stream_impl(src, dst, n, key, stream_off, device, nullptr);
+        return stream_impl(src, dst, n, key, stream_off, device, false, nullptr);
     });
 }
 

@@ -215,11 +215,14 @@ thread_local modgpu_launch_info_t t_last_launch{};
 #ifdef MODGPU_TESTING_HOOKS
 std::atomic<int> g_force_variant{-1};
 std::atomic<uint32_t> g_grid_cap{0};
+std::atomic<uint32_t> g_pcie_grid{0}; // modgpu_debug_set_pcie_grid: 0 = the product's rule
 int forced_variant() { return g_force_variant.load(std::memory_order_relaxed); }
 uint32_t forced_grid_cap() { return g_grid_cap.load(std::memory_order_relaxed); }
+uint32_t forced_pcie_grid() { return g_pcie_grid.load(std::memory_order_relaxed); }
 #else
 constexpr int forced_variant() { return -1; }
 constexpr uint32_t forced_grid_cap() { return 0; }
+constexpr uint32_t forced_pcie_grid() { return 0; }
 #endif
 
 // The device's CU count (256 on MI355X), looked up once per device: the grid of the static streaming shape (one persistent
@@ -428,6 +431,13 @@ constexpr uint64_t kLargeMin = (256ull << 20) + 1;
 // dozen workgroups of the one-word shape; more only adds contention (profiles/r02_sweep_pinned_routes.txt:
 // 4 KiB chunks, grid <= 256: 50 GB/s of payload at 64 MiB .. 4 GiB; uncapped 46; the streaming shape 41-46).
 constexpr uint32_t kPcieGridMax = 256u;
+// ... and a SHORT launch across the link -- a staged chunk of 1-8 MiB, a header -- does best with fewer still (round 5,
+// profiles/r05_pcie_grid.txt and the kernel traces beside it): with 256 workgroups every lane has its one 16-byte word in flight
+// at the same moment, 1 MiB per grid trip, so a 4 MiB chunk is four bursts of reads each followed by a burst of writes and the
+// link runs one way at a time for most of the launch; 32 workgroups (128 KiB per trip, still above the link's bandwidth-delay
+// product) turn the same chunk into a 32-trip pipeline whose reads and writes overlap.  Pageable 64 MiB: 32 -> 39-40 GB/s.
+constexpr uint32_t kPcieGridShort = 32u;
+constexpr uint64_t kPcieShortMax = 64ull << 20;
 
 // Workgroups of a work-queue launch over `chunks` chunks on a device of `cus` CUs: most main workgroups, and helpers.
 void queue_grid(uint64_t chunks, uint64_t cus, uint64_t *main_cap, uint64_t *helpers)
@@ -487,7 +497,7 @@ Plan plan_cycle(void *dev_buf, uint64_t n, uint32_t key_res, uint64_t stream_off
     uint64_t cap = p.variant == CYCLE_SMALL ? kSmallGridMax : large_grid();
     const uint32_t grid_cap = forced_grid_cap();
     if (grid_cap >= 1 && grid_cap < cap) cap = grid_cap;
-    if (over_pcie) cap = std::min<uint64_t>(cap, kPcieGridMax);
+    if (over_pcie) cap = forced_pcie_grid() ? std::min<uint64_t>(kSmallGridMax, forced_pcie_grid()) : std::min<uint64_t>(cap, body_bytes <= kPcieShortMax ? kPcieGridShort : kPcieGridMax);
     p.grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(chunks, cap));
     // one grid trip advances every lane-word by grid chunks
     a.stride_mul2 = 2u * lcg::powmod(lcg::A, ((uint64_t)p.grid * chunk) % lcg::PERIOD);
@@ -686,15 +696,16 @@ bool host_range_pinned(const void *p, uint64_t n)
 
 namespace {
 
-int cycle_host_impl(uint8_t *host, uint64_t n, int32_t key, uint64_t stream_off, int device, bool *touched)
+int cycle_host_impl(uint8_t *host, uint64_t n, int32_t key, uint64_t stream_off, int device, bool host_may_finish = false,
+                    StreamOutcome *out = nullptr)
 {
-    if (touched) *touched = false;
+    if (out) *out = StreamOutcome{};
     if (n == 0) return MODGPU_OK;
     if (!host) return fail(MODGPU_ERR_INVALID, "null host buffer");
     Endpoint e;
     e.mem = host;
     e.pinned = host_range_pinned(host, n);
-    return stream_impl(e, e, n, key, stream_off, device, touched);
+    return stream_impl(e, e, n, key, stream_off, device, host_may_finish, out);
 }
 
 int scalar_impl(uint8_t *host, uint64_t n, int32_t key, uint64_t stream_off, int isa = MODGPU_ISA_AUTO)
@@ -757,7 +768,7 @@ int modgpu_cycle_batch_device(void *const *dev_parts, const uint64_t *sizes, con
 
 int modgpu_cycle_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, int device)
 {
-    return guarded([&]() -> int { return cycle_host_impl(host_buf, n, key, stream_off, device, nullptr); });
+    return guarded([&]() -> int { return cycle_host_impl(host_buf, n, key, stream_off, device); });
 }
 
 int modgpu_cycle_scalar_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off)
@@ -783,13 +794,17 @@ static int cycle_auto_impl(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t 
         if (rc == MODGPU_OK) g_stats.auto_policy_host.fetch_add(1, std::memory_order_relaxed);
         return rc;
     }
-    bool touched = false;
-    int rc = cycle_host_impl(host_buf, n, key, stream_off, device, &touched);
+    // The reference's Cycle cannot fail (CEncryptionCycler.cpp:4-14; its callers at CArk.cpp:338-339, 1135-1136 and
+    // Modulate.cpp:485-486 do not guard it).  A GPU lost AFTER the call has begun is handled inside the route: the staged route
+    // knows which pieces have reached host_buf and lets the host loop do the others (host_stream.cpp).
+    StreamOutcome outcome;
+    int rc = cycle_host_impl(host_buf, n, key, stream_off, device, /*host_may_finish=*/!gpu_required(), &outcome);
+    if (rc == MODGPU_OK && outcome.finished_on_host) g_stats.auto_fallbacks.fetch_add(1, std::memory_order_relaxed);
     if (rc == MODGPU_OK || rc == MODGPU_ERR_INVALID) return rc;
-    // No GPU, or the GPU attempt failed.  The reference's Cycle cannot fail: finish on the host --
-    // unless the caller forbade that, or the failed attempt may already have written part of the
-    // result into host_buf (starting over would cycle those bytes twice).
-    if (gpu_required() || touched) return rc;
+    // No GPU, or the attempt failed before it had changed host_buf: the host loop does the whole buffer.  What is left as an
+    // error: the caller forbade the host loop, or one kernel working in place on page-locked caller memory died under way --
+    // nobody knows which bytes it had written and the plaintext exists nowhere else.
+    if (gpu_required() || outcome.touched) return rc;
     const std::string why = t_err;
     rc = scalar_impl(host_buf, n, key, stream_off);
     if (rc == MODGPU_OK) g_stats.auto_fallbacks.fetch_add(1, std::memory_order_relaxed);
@@ -839,7 +854,7 @@ static int parts_host_impl(uint8_t *const *parts, const uint64_t *sizes, const u
     auto body = [&](int d, bool own_thread) {
         if (own_thread) run_near_device(d); // this worker's copies run on the socket its GPU hangs off
         for (int i = d; i < n_parts; i += n_devices) { // part i -> GPU i mod N
-            int rc = cycle_host_impl(parts[i], sizes[i], key, offs ? offs[i] : 0, d, nullptr);
+            int rc = cycle_host_impl(parts[i], sizes[i], key, offs ? offs[i] : 0, d);
             if (rc) {
                 rcs[d] = rc;
                 errs[d] = t_err;
@@ -1150,6 +1165,8 @@ int modgpu_path_stats(modgpu_path_stats_t *out, int reset)
     out->staged_bytes = take(g_stats.staged_bytes);
     out->direct_bytes = take(g_stats.direct_bytes);
     out->auto_fallbacks = take(g_stats.auto_fallbacks);
+    out->midcall_rescues = take(g_stats.midcall_rescues);
+    out->midcall_rescued_bytes = take(g_stats.midcall_rescued_bytes);
     out->auto_small = take(g_stats.auto_small);
     out->auto_policy_host = take(g_stats.auto_policy_host);
     return MODGPU_OK;
@@ -1332,6 +1349,7 @@ void modgpu_debug_set_launch(int variant, uint32_t grid_cap)
     g_grid_cap.store(grid_cap, std::memory_order_relaxed);
 }
 
+void modgpu_debug_set_pcie_grid(uint32_t cap) { g_pcie_grid.store(cap, std::memory_order_relaxed); }
 void modgpu_debug_set_pinned_mode(int mode) { g_pinned_mode.store(mode, std::memory_order_relaxed); }
 void modgpu_debug_set_staged_mode(int mode) { g_staged_mode.store(mode, std::memory_order_relaxed); }
 

@@ -79,7 +79,7 @@ int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_of
 // ---- which engine ran -------------------------------------------------------------------------
 struct Stats {
     std::atomic<uint64_t> gpu_calls{0}, gpu_bytes{0}, gpu_launches{0}, scalar_calls{0}, scalar_bytes{0},
-        staged_bytes{0}, direct_bytes{0}, auto_fallbacks{0}, auto_small{0}, auto_policy_host{0};
+        staged_bytes{0}, direct_bytes{0}, auto_fallbacks{0}, auto_small{0}, auto_policy_host{0}, midcall_rescues{0}, midcall_rescued_bytes{0};
 };
 extern Stats g_stats;
 bool gpu_required(); // MODGPU_REQUIRE_GPU=1 at load
@@ -97,10 +97,18 @@ struct Endpoint {
     uint64_t base = 0;
     bool pinned = false;    // mem is page-locked and device-visible: DMA'd directly, no staging copy
 };
-// src -> GPU -> dst for n bytes.  *touched (optional) is set once dst may have been modified, so a
-// caller with a second engine knows whether it can still start over.
+struct Piece { uint64_t off, len; }; // a span of a stream, in stream bytes
+// What a call did besides succeeding or failing.
+struct StreamOutcome {
+    bool touched = false;          // dst may differ from what it was: a caller with a second engine can no longer simply start over
+    bool finished_on_host = false; // the GPU was lost after the call had begun and the host loop did the pieces whose result had
+                                   // not reached dst (rc is MODGPU_OK then)
+    uint64_t host_bytes = 0;       // ... that many bytes
+};
+// src -> GPU -> dst for n bytes.  host_may_finish: on a HIP failure after the call has begun, finish the undone pieces with the
+// library's host loop where their plaintext still exists (host_stream.cpp: stream_impl's end says where it does not).
 int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t key, uint64_t stream_off, int device,
-                bool *touched);
+                bool host_may_finish, StreamOutcome *out);
 #ifdef MODGPU_TESTING_HOOKS
 extern std::atomic<int> g_pinned_mode; // modgpu_debug_set_pinned_mode
 extern std::atomic<int> g_staged_mode; // modgpu_debug_set_staged_mode

@@ -194,8 +194,10 @@ unsigned max_threads()
 unsigned cgroup_cpu_limit()
 {
     static const unsigned v = [] {
-        if (const char *e = std::getenv("MODGPU_HOST_CGROUP")) // MODGPU_HOST_CGROUP=0: do not look (short bursts are not throttled)
+#ifdef MODGPU_TESTING_HOOKS // (testing flavour only: MODGPU_HOST_CGROUP=0 = do not look -- short bursts are not throttled; a measurement switch)
+        if (const char *e = std::getenv("MODGPU_HOST_CGROUP"))
             if (std::strcmp(e, "0") == 0) return 0u;
+#endif
         auto read2 = [](const char *path, long long *a, long long *b) {
             FILE *f = std::fopen(path, "r");
             if (!f) return 0;
@@ -227,7 +229,7 @@ std::vector<int> allowed_cpus()
         if (CPU_ISSET(c, &set)) cpus.push_back(c);
     return cpus;
 }
-// MODGPU_HOST_SPREAD=1: bind each worker to a CPU of its own for the length of its span.  OFF by default since round 4: the
+// MODGPU_HOST_SPREAD=1 (testing flavour): bind each worker to a CPU of its own for the length of its span.  OFF by default since round 4: the
 // workers are parked threads now, which the scheduler wakes on idle CPUs all over the caller's mask, and for this memory-bound
 // loop that is the better placement -- 16 unbound workers reach 113-180 GB/s at 16 MiB ... 1 GiB on the MI355X node's EPYC 9575F,
 // 16 workers bound to the CPUs next to the caller's 79-110 (neighbouring CPU numbers are cores of one or two CCDs, which share
@@ -235,11 +237,15 @@ std::vector<int> allowed_cpus()
 // per call, and short-lived threads the scheduler is left to place can sit on one CPU for their whole life (measured in a VM).
 bool spread_enabled()
 {
+#ifdef MODGPU_TESTING_HOOKS // (a measurement switch of the testing flavour; the shipped library never binds its workers)
     static const bool v = [] {
         const char *e = std::getenv("MODGPU_HOST_SPREAD");
         return e && std::strcmp(e, "1") == 0;
     }();
     return v;
+#else
+    return false;
+#endif
 }
 
 // ---- parked workers ---------------------------------------------------------------------------------------------------------

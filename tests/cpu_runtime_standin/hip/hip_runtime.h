@@ -1,4 +1,4 @@
-// hip_shim/hip/hip_runtime.h -- NOT part of the product, and NOT a compatibility layer for it.
+// tests/cpu_runtime_standin/hip/hip_runtime.h -- NOT part of the product, and NOT a compatibility layer for it.
 //
 // A CPU stand-in for the handful of HIP runtime calls libmodgpu.so's HOST code makes (modgpu_capi.cpp,
 // host_stream.cpp), used by `make sanitize-lib` only: GPU AddressSanitizer / ThreadSanitizer do not exist on
@@ -9,7 +9,7 @@
 //   streams   real in-order queues, each drained by its own thread: work on two streams really overlaps,
 //             so ThreadSanitizer sees the same interleavings the GPU runtime would produce
 //   memory    device / pinned memory = ordinary host memory; copies = memcpy on the stream's thread
-//   launch    the product's host loop on the span the launch plan describes (shim_launch.cpp) -- with the
+//   launch    the product's host loop on the span the launch plan describes (standin_launch.cpp) -- with the
 //             work-queue shape's ticket-pair protocol emulated, so a pair handed to two overlapping launches is
 //             detected (modgpu_shim_pair_collisions)
 //   devices   MODGPU_SHIM_DEVICES of them (default 2): per-thread current device like HIP's
@@ -17,7 +17,7 @@
 #include <cstddef>
 #include <cstdint>
 
-enum hipError_t : int { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorInvalidDevice = 101, hipErrorUnknown = 999 };
+enum hipError_t : int { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorInvalidDevice = 101, hipErrorLaunchFailure = 719, hipErrorUnknown = 999 };
 struct ShimStream;
 struct ShimEvent;
 using hipStream_t = ShimStream *;
@@ -61,7 +61,7 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 
-// shim internals shared with shim_launch.cpp
+// shim internals shared with standin_launch.cpp
 namespace shim {
 void enqueue(hipStream_t s, void (*fn)(void *), void *arg); // runs fn(arg) on the stream's thread, in order; s == nullptr: the current device's null stream
 }

@@ -5,8 +5,8 @@
 // scalar_path.cpp, compiled into the same build, so it runs under the sanitizers too.
 #include <cstdlib>
 
-#include "../../../include/modgpu.h"
-#include "../scalar_path.h"
+#include "../../include/modgpu.h"
+#include "../../modulate_amd/csrc/scalar_path.h"
 
 extern "C" {
 const char* modgpu_last_error( void ) { return "sanitizer stub: no HIP device"; }

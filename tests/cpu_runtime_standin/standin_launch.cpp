@@ -1,4 +1,4 @@
-// shim_launch.cpp -- the launch side of the CPU stand-in (hip_shim/hip/hip_runtime.h): cycle_kernel.h's interface
+// standin_launch.cpp -- the launch side of the CPU stand-in (tests/cpu_runtime_standin/hip/hip_runtime.h): cycle_kernel.h's interface
 // implemented on the host.  A "launch" is queued on the stream's thread and does, from the launch PLAN alone
 // (CycleArgs: head / body / tail pointers, the three base states, `lead`), what the kernel would do to the same
 // bytes -- with the product's own Park-Miller arithmetic (lcg.h), byte by byte.  So the sanitizer runs check the
@@ -9,8 +9,8 @@
 #include <chrono>
 #include <thread>
 
-#include "../cycle_kernel.h"
-#include "../lcg.h"
+#include "../../modulate_amd/csrc/cycle_kernel.h"
+#include "../../modulate_amd/csrc/lcg.h"
 
 namespace {
 std::atomic<unsigned long long> g_collisions{0}, g_launches[kCycleVariants] = {};

@@ -1,4 +1,4 @@
-// shim_runtime.cpp -- see hip_shim/hip/hip_runtime.h.  CPU build for the sanitizers only.
+// standin_runtime.cpp -- see tests/cpu_runtime_standin/hip/hip_runtime.h.  CPU build for the sanitizers only.
 #include <hip/hip_runtime.h>
 
 #include <atomic>

@@ -2,7 +2,7 @@
 
 Not collected by a plain `pytest tests/`: tests/test_sanitizers.py runs this file in a child process with
 MODGPU_LIB pointing at _san/libmodgpu_asan.so or _san/libmodgpu_tsan.so and the matching runtime preloaded.
-Those builds link hip_shim/ instead of the HIP runtime: streams are real threads, a "launch" executes the launch
+Those builds link tests/cpu_runtime_standin/ instead of the HIP runtime: streams are real threads, a "launch" executes the launch
 plan with the product's own arithmetic on the CPU, eight devices exist.  What runs under the sanitizers is
 therefore exactly the code that cannot be sanitized on the GPU: launch planning, the ticket ring, the host-range
 table, the staging pipelines' retire / refill state machine and their error paths, per-device contexts, worker
@@ -44,6 +44,7 @@ def hooks(lib):
             M.debug_set_helpers(0)
             M.debug_set_batch(0)
             M.debug_inject_failures(0)
+            M.debug_inject_failure_at(0, -1)
 
 
 def want(pt, key, off=0):
@@ -310,6 +311,25 @@ def test_injected_failures_and_the_second_engine(hooks):
     assert np.array_equal(M.cycle_auto_host(small.copy(), M.KEY_PS4), want(small, M.KEY_PS4))
     st = M.path_stats()
     assert st["auto_fallbacks"] == 1 and st["auto_small"] == 1 and st["scalar_calls"] == 2 and st["gpu_calls"] == 1, st
+
+
+def test_gpu_lost_in_the_middle_of_a_call(hooks, tmp_path):
+    """a failure injected at piece 0 / the middle piece / the last, at every stage (fill, launch, sync, drain, after
+    the drain), of a staged call of 8 pipelines: the sibling pipelines stop, the host loop finishes exactly the pieces that have
+    not arrived, the bytes are the reference's; the strict entry point returns the error; page-locked memory in place keeps its
+    error once the kernel runs; modgpu_cycle_file_to_host reads the lost pieces again.  (tests/_midcall_child.py, in this process:
+    the same script the GPU suite runs against the real runtime.)"""
+    import runpy
+    import sys
+    argv = sys.argv
+    sys.argv = ["_midcall_child.py", "12,33", "--files", str(tmp_path)]
+    try:
+        with pytest.raises(SystemExit) as e:
+            runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_midcall_child.py"), run_name="__main__")
+        assert e.value.code == 0
+    finally:
+        sys.argv = argv
+        M.debug_inject_failure_at(0, -1)
 
 
 def test_ticket_ring_under_concurrent_streams(hooks, lib):

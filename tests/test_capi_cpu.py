@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(modgpu):
     assert modgpu.active_flavour() == "shipped" and not modgpu.testing_hooks()
     for name in list(modgpu.EXPORTS) + list(modgpu.TESTING_EXPORTS):
         assert getattr(L, name) is not None
-    assert L.modgpu_abi_version() == 6
+    assert L.modgpu_abi_version() == 7
 
     def exported(path):
         out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
@@ -457,7 +457,8 @@ def test_lab_kernel_at_the_products_settings_is_the_products_loop():
      {"pipes": 16, "chunk_bytes": 1 << 20, "ring": 4, "zerocopy_max_bytes": 0}),
 ])
 def test_host_tunables_are_clamped_at_load(env, want):
-    code = "import json, modulate_amd as M; print('T', json.dumps(M.host_tunables()))"
+    # (MODGPU_HOST_ZEROCOPY_KB and _RING are knobs of the testing flavour only since round 5; _PIPES and _CHUNK_MB of both)
+    code = "import json, modulate_amd as M; M.use_testing_flavour(); print('T', json.dumps(M.host_tunables()))"
     e = {k: v for k, v in os.environ.items() if not k.startswith("MODGPU_HOST_")}
     e.update(env, PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, cwd=ROOT)
@@ -467,6 +468,34 @@ def test_host_tunables_are_clamped_at_load(env, want):
     for k, v in want.items():
         assert got[k] == v, (k, got)
     assert got["zerocopy_max_bytes"] <= got["chunk_bytes"]
+
+
+def test_environment_of_the_shipped_library_is_what_the_header_lists():
+    """the variables libmodgpu.so reads are exactly the ones include/modgpu.h documents (ten); the staging and
+    host-loop measurement knobs exist in the testing flavour only, and the shipped library ignores them."""
+    import re
+    def names(path):
+        out = subprocess.run(["strings", "-a", path], capture_output=True, text=True, check=True).stdout
+        return {w for w in out.split() if re.fullmatch(r"MODGPU_[A-Z0-9_]+", w) and not w.startswith(("MODGPU_ERR", "MODGPU_ISA", "MODGPU_KERNEL", "MODGPU_TESTING"))}
+    shipped = names(os.path.join(ROOT, "modulate_amd", "libmodgpu.so"))
+    header = open(os.path.join(ROOT, "include", "modgpu.h")).read()
+    block = header[header.index(" * Environment (each read once"):header.index("#ifndef MODGPU_H")]
+    listed = set(re.findall(r"^ \*     (MODGPU_[A-Z0-9_]+)", block, flags=re.M))
+    assert shipped == listed == {"MODGPU_REQUIRE_GPU", "MODGPU_MIN_GPU_BYTES", "MODGPU_HOST_POLICY", "MODGPU_HOST_THREADS", "MODGPU_HOST_ISA", "MODGPU_DEVICE_ALIAS",
+                                 "MODGPU_NUMA", "MODGPU_HELPER_BELOW_MHZ", "MODGPU_HOST_PIPES", "MODGPU_HOST_CHUNK_MB"}, (sorted(shipped), sorted(listed))
+    testing = names(os.path.join(ROOT, "modulate_amd", "libmodgpu_testing.so"))
+    assert testing - shipped == {"MODGPU_HOST_ZEROCOPY_KB", "MODGPU_HOST_RING", "MODGPU_HOST_SPLIT", "MODGPU_HOST_CHUNK_MIN_MB", "MODGPU_HOST_RAMP_KB", "MODGPU_HOST_LANES",
+                                  "MODGPU_HOST_NTCOPY", "MODGPU_HOST_SPREAD", "MODGPU_HOST_CGROUP"}, sorted(testing - shipped)
+    code = ("import json, modulate_amd as M; a = [M.host_tunables(), M.host_chunking()]; M.use_testing_flavour(); "
+            "print('T', json.dumps([a, [M.host_tunables(), M.host_chunking()]]))")
+    e = {k: v for k, v in os.environ.items() if not k.startswith("MODGPU_HOST_")}
+    e.update(PYTHONPATH=ROOT, MODGPU_HOST_ZEROCOPY_KB="64", MODGPU_HOST_LANES="1", MODGPU_HOST_RAMP_KB="0", MODGPU_HOST_SPLIT="99", MODGPU_HOST_RING="2")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import json
+    (st, sc), (tt, tc) = json.loads(r.stdout.split("T ", 1)[1])
+    assert st["zerocopy_max_bytes"] == 1 << 20 and st["ring"] == 4 and sc["lanes"] == 4 and sc["ramp_bytes"] == 1 << 20 and sc["split"] == 16, (st, sc)
+    assert tt["zerocopy_max_bytes"] == 64 << 10 and tt["ring"] == 2 and tc["lanes"] == 1 and tc["ramp_bytes"] == 0 and tc["split"] == 99, (tt, tc)
 
 
 def test_headers_are_plain_c_and_link_standalone(tmp_path):

@@ -402,6 +402,26 @@ def test_auto_entry_point_when_a_gpu_call_fails(gpu, strict):
     assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("case", ["auto_64MiB_1GiB", "class_64MiB", "strict_64MiB"])
+def test_gpu_lost_in_the_middle_of_a_call(gpu, case):
+    """VERDICT r4 #1.  The reference's Cycle returns void and cannot fail (CEncryptionCycler.h:6, .cpp:4-14) and its callers do not
+    guard it (CArk.cpp:338-339, 1135-1136, Modulate.cpp:485-486).  A failure is injected at piece 0, the middle piece and the last,
+    at each stage (fill, launch, sync, drain, after the drain) of a staged call over pageable memory -- 64 MiB and 1 GiB: the
+    sibling pipelines stop, the host loop does exactly the pieces that have not reached the buffer, the result is the oracle's,
+    modgpu_path_stats counts the rescue.  `class`: the same through CEncryptionCycler::Cycle itself (the host mirror bound to the
+    testing flavour by preloading it), which must return normally.  `strict`: with MODGPU_REQUIRE_GPU=1 nothing computes on the
+    host and the error comes back.  Also in the child: page-locked memory in place (launch failure -> whole buffer on the host
+    loop; kernel dies under way -> the one documented error), header-sized buffers, modgpu_cycle_file_to_host on pageable and
+    page-locked destinations (tests/_midcall_child.py)."""
+    env = dict(os.environ, MODGPU_REQUIRE_GPU="1" if case.startswith("strict") else "0", MODGPU_MIN_GPU_BYTES="65536")
+    args = [sys.executable, os.path.join(ROOT, "tests", "_midcall_child.py"), "64,1024" if case.startswith("auto") else "64", "--files", "/dev/shm"]
+    if case.startswith("class"):
+        args.append("--class")
+        env["LD_PRELOAD"] = os.path.join(ROOT, "modulate_amd", "libmodgpu_testing.so")  # libmodulate_host.so's modgpu_* references bind to it
+    r = subprocess.run(args, capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0 and "MIDCALL_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 FUZZ_CASES = [("large", 1), ("large", 2), ("large", 3), ("large", 7), ("large", None), ("small", 1), ("small", 5), ("small", None),
               ("queue", 1), ("queue", 2), ("queue", 3), ("queue", 5), ("queue", 16), ("queue", None)]
 

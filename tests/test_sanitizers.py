@@ -44,11 +44,11 @@ def _san_lib_cases(preload, lib, extra_env):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "san_lib_cases.py"), "-x", "-q", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=ROOT, timeout=1500)
-    assert r.returncode == 0 and "9 passed" in r.stdout, r.stdout[-4000:] + r.stderr[-4000:]
+    assert r.returncode == 0 and "10 passed" in r.stdout, r.stdout[-4000:] + r.stderr[-4000:]
 
 
 def test_library_host_code_under_asan_ubsan():
-    """libmodgpu's own threaded host code (modgpu_capi.cpp, host_stream.cpp) built against hip_shim/ -- a CPU
+    """libmodgpu's own threaded host code (modgpu_capi.cpp, host_stream.cpp) built against tests/cpu_runtime_standin/ -- a CPU
     stand-in for the HIP runtime whose streams are real threads -- with ASan + UBSan, driven by tests/san_lib_cases.py:
     launch planning at every shape, staged pipelines and both route forms, pinned / registered / placed memory, file routes
     and their error paths, eight workers on eight devices, failure injection, the ticket ring under two concurrent streams."""

@@ -42,7 +42,9 @@ def main():
     ap.add_argument("--arks", type=int, default=8)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "configs.json"))
     ap.add_argument("--tmp", default="/dev/shm")
+    ap.add_argument("--sections", default="host,c1,c4,c5", help="comma list of host, c1, c4, c5 (c5 needs c4); e.g. c4 alone under a profiler")
     a = ap.parse_args()
+    sections = set(a.sections.split(","))
     import modulate_amd as M
     from modulate_amd import host as H
     assert M.device_count() >= 1
@@ -52,7 +54,7 @@ def main():
     # ---- host-buffer path (PCIe-inclusive): modgpu_cycle_host on pageable memory
     M.cycle_host(np.zeros(1 << 20, np.uint8), M.KEY_PS4)  # create the staging context
     hp = {}
-    for n in (4096, 256 << 10, 64 << 20, 1 << 30, 1 << 32):
+    for n in (4096, 256 << 10, 64 << 20, 1 << 30, 1 << 32) if "host" in sections else ():
         buf = rng.integers(0, 256, size=min(n, 1 << 26), dtype=np.uint8)
         buf = np.resize(buf, n)
         reps = 200 if n <= (256 << 10) else (5 if n <= (64 << 20) else 3)
@@ -66,7 +68,7 @@ def main():
     res["host_path"] = hp
     # the same on page-locked caller memory (modgpu_host_alloc: what CArk's part buffer is): no staging copy
     hpp = {}
-    for n in (64 << 20, 411 << 20, 1 << 30, 1 << 32):
+    for n in (64 << 20, 411 << 20, 1 << 30, 1 << 32) if "host" in sections else ():
         pb = M.PinnedBuffer(n + 64)
         pb.array[:] = 7
         view = pb.array[4:4 + n]
@@ -84,20 +86,21 @@ def main():
     body = rng.integers(0, 256, size=4092, dtype=np.uint8)
     hdr = np.concatenate([np.zeros(4, np.uint8), body])
     M.hdr_encrypt_host(hdr, True)
+    c1 = 2000 if "c1" in sections else 1
     t0 = time.perf_counter()
-    for _ in range(2000):
+    for _ in range(c1):
         M.hdr_decrypt_host(hdr)
         M.hdr_encrypt_host(hdr, True)
     res["config1_4k_hdr_roundtrip_us"] = round((time.perf_counter() - t0) / 2000 * 1e6, 2)  # framing entry points: Cycle's dispatch
     t0 = time.perf_counter()
-    for _ in range(200):
+    for _ in range(200 if "c1" in sections else 1):
         M.cycle_host(hdr[4:], M.KEY_PS4)
         M.cycle_host(hdr[4:], M.KEY_PS4)
     res["config1_4k_kernel_roundtrip_us"] = round((time.perf_counter() - t0) / 200 * 1e6, 1)  # the kernel route, forced (modgpu_cycle_host)
     # what the reference's call sites bind to: CEncryptionCycler::Cycle -> modgpu_cycle_auto_host (size dispatch: the host loop here)
     before = M.path_stats()
     t0 = time.perf_counter()
-    for _ in range(2000):
+    for _ in range(c1):
         H.cycle_via_class(hdr[4:], M.KEY_PS4)
         H.cycle_via_class(hdr[4:], M.KEY_PS4)
     res["config1_4k_Cycle_roundtrip_us"] = round((time.perf_counter() - t0) / 2000 * 1e6, 2)
@@ -105,6 +108,9 @@ def main():
     res["config1_engine"] = {"auto_small_calls": after["auto_small"] - before["auto_small"], "gpu_calls": after["gpu_calls"] - before["gpu_calls"],
                              "min_gpu_bytes": M.min_gpu_bytes(), "host_loop_isa": M.host_loop_isa()}
 
+    if not sections & {"c4", "c5"}:
+        print(json.dumps(res, indent=1))
+        return
     # ---- config 4: 100k synthetic entries -> multi-part .ark + encrypted header, 1 GPU
     tm = T()
     names = [f"dir{k % 97}/sub{k % 13}/f{k}.bin" for k in range(a.entries)]
@@ -138,6 +144,8 @@ def main():
         # (parity of the header image and of the part cipher is asserted in tests/test_host_gpu.py;
         #  this script only times, and checks the round trip below for self-consistency)
 
+        if "c5" not in sections:
+            raise StopIteration
         # ---- config 5: decrypt -> unpack -> repack -> encrypt, byte-diff
         tm5 = T()
         unpacked = os.path.join(work, "unpacked") + "/"
@@ -180,6 +188,8 @@ def main():
                        for k in range(0, a.entries, max(1, a.entries // 2000)))
         res["config5"] = {"seconds": dict(tm5.t), "roundtrip_byte_identical": same, "extracted_files_match": bool(ok_files),
                           "total_seconds": round(sum(tm5.t.values()), 3)}
+    except StopIteration:
+        pass
     finally:
         shutil.rmtree(work, ignore_errors=True)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
