@@ -197,7 +197,11 @@ int modgpu_cycle_host_split(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t
 /* The same for parts that are already resident in HBM, part i on GPU devices[i] (BASELINE config 3: 8 x 4 GiB,
  * one per GPU).  The launches are asynchronous, so the calling thread alone keeps every GPU busy; the call
  * returns when all of them have finished.  No inter-GPU traffic.  Parts that share a GPU go to it through
- * modgpu_cycle_batch_device. */
+ * modgpu_cycle_batch_device.
+ * Ordering: the kernels run on a stream of the library's own per device (non-blocking).  Work the caller queued BEFORE the call
+ * on a device's NULL stream or on any of its blocking streams -- an asynchronous upload or memset of a part, a kernel that
+ * produces it -- is finished before that device's parts are cycled (the library's stream waits for an event recorded on the
+ * NULL stream at entry).  Work on the caller's own NON-blocking streams is not ordered: synchronise those before the call. */
 int modgpu_cycle_parts_device(void *const *dev_parts, const uint64_t *sizes, const int *devices, int n_parts, int32_t key);
 
 /* ---- part files streamed through the GPU ----------------------------

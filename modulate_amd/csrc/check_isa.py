@@ -9,7 +9,7 @@ its output, so the output is what is checked:
   * nothing outside the blocks touches the fixed registers, and no operand the compiler chose for a block lies in them
     (round 3: as plain clobbers the allocator handed them to inputs of the block -- wrong keystream, no error);
   * every block ends with the s_nop 0 that covers the SDWA dst_sel forwarding hazard towards the compiler's next instruction;
-  * register counts stay inside the budget, nothing spills, no scratch;
+  * register counts stay inside the budget (the small shape: <= 64 VGPRs, 8 waves per SIMD), nothing spills, no scratch;
   * the work-queue kernel's ticket fetch is still ONE plain returning atomic per trip (LLVM's atomic optimizer would turn it
     into a wave-aggregated atomic followed at once by s_waitcnt vmcnt(0)), its mailbox is accessed with ds_ instructions,
     loads are nt, stores nt sc1, and the part table is read from the kernel arguments (no private segment).
@@ -55,6 +55,10 @@ def check(asm):
             bad.append("%s: spills or a private segment: %s" % (name, md))
         if "scratch_" in fn:
             bad.append("%s: scratch instructions" % name)
+        # the small shape (one word per lane, launch-latency-bound sizes and every launch across PCIe) lives on occupancy: it has
+        # no pipeline of its own, so it must keep 8 waves per SIMD, i.e. at most 64 VGPRs (512 per SIMD lane / 8)
+        if "modgpu_cycle_kernelILi1ELi256E" in name and md.get("vgpr_count", 999) > 64:
+            bad.append("%s: the small shape needs %d VGPRs -- more than 64, fewer than 8 waves per SIMD" % (name, md.get("vgpr_count", 999)))
         blocks = BLOCK.findall(fn)
         carry = [b for b in blocks if "s[94:95]" in b]
         if not carry:

@@ -30,6 +30,7 @@
 // call at 16-64 MiB, and concurrent callers ran strictly one after the other.  modgpu_host_trace (modgpu_testing.h) records
 // every step of a call with a timestamp; bin/modbench --hostcall --trace prints the timeline.
 #include <fcntl.h>
+#include <pthread.h>
 #include <sys/stat.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -101,15 +102,18 @@ constexpr int kPipeSlots = 32; // ... + 2 that only one-slot calls may take: a 4
 // not twenty:
 //   zero_copy_max  largest buffer cycled in one pinned slot by one kernel, no chunking (1 MiB; never larger than a slot)
 //   ring           device slots in flight on the DMA form of the pinned route (4)
-//   split          a buffer is cut into about this many chunks ...                                   (16)
-//   chunk_min      ... of at least this many bytes (and at most a slot)                               (2 MiB)
+//   split          a buffer is cut into about this many chunks ...                                   (64; 16 until round 5)
+//   chunk_min      ... of at least this many bytes (and at most a slot)                               (1 MiB; 2 MiB until round 5)
 //   ramp           each pipeline's FIRST and LAST chunk are this small (0 = all alike): nothing crosses the link while the first
-//                  chunks are being copied in, nor while the last ones are copied out                 (1 MiB)
+//                  chunks are being copied in, nor while the last ones are copied out                 (512 KiB; 1 MiB until round 5)
 //   lanes          streams a call's kernels-across-PCIe are queued on, in launch order, round robin (0 = every slot its own
 //                  stream, the round-3 form: the GPU then runs all 16 chunk kernels of a call at once, each on a sixteenth of the
 //                  link, and they all finish late together, profiles/r04_staged_midsize.txt)           (4 since round 5)
 //   nt_copy        the staging copies use non-temporal stores (1)
-// Chunking defaults: profiles/r04_staged_midsize.txt (16 ... 256 MiB, pageable, settings interleaved); lanes: profiles/r05_pcie_grid.txt.
+// Chunking defaults: profiles/r05_pcie_grid.txt (16 ... 256 MiB, pageable, settings interleaved).  Round 4 had ~16 chunks of >= 2 MiB behind
+// a 1 MiB ramp on 2 lanes, chosen while a chunk's kernel across the link ran at 45 % of the link's rate; with the short-launch grid of
+// round 5 (modgpu_capi.cpp: kPcieGridShort) a 1-4 MiB kernel is efficient, and finer chunks -- more overlap of copy-in, link and
+// copy-out -- win again: 16 / 64 / 256 MiB 34.9 / 42.5 / 45.5 GB/s with round 4's cut, 38.6 / 44.6 / 46.8 with this one.
 int env_int(const char *name, int dflt, int lo, int hi)
 {
     const char *v = std::getenv(name);
@@ -128,9 +132,9 @@ const int kPipes = env_int("MODGPU_HOST_PIPES", 8, 1, kMaxPipes);
 const uint64_t kChunk = (uint64_t)env_int("MODGPU_HOST_CHUNK_MB", 8, 1, 256) << 20;
 MODGPU_KNOB_STORAGE uint64_t kZeroCopyMax = std::min<uint64_t>((uint64_t)MODGPU_KNOB("MODGPU_HOST_ZEROCOPY_KB", 1024, 0, 1 << 20) << 10, kChunk);
 MODGPU_KNOB_STORAGE int kRing = MODGPU_KNOB("MODGPU_HOST_RING", 4, 2, 4);
-MODGPU_KNOB_STORAGE uint64_t kSplit = (uint64_t)MODGPU_KNOB("MODGPU_HOST_SPLIT", 16, 2, 256);
-MODGPU_KNOB_STORAGE uint64_t kChunkMin = std::min<uint64_t>((uint64_t)MODGPU_KNOB("MODGPU_HOST_CHUNK_MIN_MB", 2, 1, 256) << 20, kChunk);
-MODGPU_KNOB_STORAGE uint64_t kRamp = std::min<uint64_t>((uint64_t)MODGPU_KNOB("MODGPU_HOST_RAMP_KB", 1024, 0, 1 << 18) << 10, kChunk);
+MODGPU_KNOB_STORAGE uint64_t kSplit = (uint64_t)MODGPU_KNOB("MODGPU_HOST_SPLIT", 64, 2, 256);
+MODGPU_KNOB_STORAGE uint64_t kChunkMin = std::min<uint64_t>((uint64_t)MODGPU_KNOB("MODGPU_HOST_CHUNK_MIN_MB", 1, 1, 256) << 20, kChunk);
+MODGPU_KNOB_STORAGE uint64_t kRamp = std::min<uint64_t>((uint64_t)MODGPU_KNOB("MODGPU_HOST_RAMP_KB", 512, 0, 1 << 18) << 10, kChunk);
 MODGPU_KNOB_STORAGE int kLanes = MODGPU_KNOB("MODGPU_HOST_LANES", 4, 0, 8);
 MODGPU_KNOB_STORAGE bool kNtCopy = MODGPU_KNOB("MODGPU_HOST_NTCOPY", 1, 0, 1) != 0;
 constexpr int kFileLanes = 0; // calls with a file on either side keep a stream per slot: lanes made no difference there (profiles/r04_file_routes.txt)
@@ -167,7 +171,10 @@ struct Staging {
     std::deque<std::shared_ptr<Call>> requests; // under mu: one entry per pipeline a call would like a worker for
     int workers = 0, parked = 0;                // under mu
 };
-Staging *const g_staging = new Staging[kMaxDevices];
+Staging *g_staging = new Staging[kMaxDevices];
+// fork(): the child has neither the parked workers nor a usable HIP context; it starts with fresh, empty staging contexts (the
+// old ones, whose mutexes a vanished thread may hold, are leaked on purpose).  ADVICE r4.
+const int g_staging_atfork = ::pthread_atfork(nullptr, nullptr, [] { g_staging = new Staging[kMaxDevices]; });
 std::atomic<uint64_t> g_pool_spawned{0}, g_pool_tasks{0}, g_slot_waits{0}, g_calls_in_flight{0}, g_calls_overlapped{0};
 
 // Slots a call owns, given back (and waiters woken) when the call ends, whichever way.
@@ -725,6 +732,10 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
         trace(MODGPU_TRACE_POSTED, -1, (uint64_t)pipes, 0);
         call->help(false); // pipeline 0 starts now, on the calling thread; then whatever no worker has picked up yet
         call->wait();
+        { // entries of this call that no worker has picked up are of no use to anybody now
+            std::lock_guard<std::mutex> lock(s.mu);
+            s.requests.erase(std::remove(s.requests.begin(), s.requests.end(), call), s.requests.end());
+        }
         for (int p = 0; p < pipes && rc == MODGPU_OK; ++p)
             if (call->rcs[(size_t)p]) {
                 t_err = call->errs[(size_t)p];

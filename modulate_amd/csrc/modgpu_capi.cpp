@@ -918,17 +918,43 @@ int modgpu_cycle_host_split(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t
 // not on the legacy NULL stream: that one synchronises implicitly with every blocking stream of the process, so a caller with
 // work of its own on such streams would get a serialisation it did not ask for (VERDICT r3 weak #9b).  Concurrent calls share the
 // device's stream: their launches queue behind each other, and each waits for all of them.
-static hipStream_t parts_stream(int logical)
+// What the NULL stream did give a caller is kept: work the caller queued BEFORE the call on the NULL stream or on any
+// blocking stream -- an asynchronous upload or memset of a part, a producer kernel, torch's default stream -- is finished before
+// the cycle kernels start.  An event recorded on the NULL stream at entry stands for all of that (the legacy stream waits for
+// every blocking stream), and the private stream waits for the event: the caller's earlier work is ordered in front of the parts'
+// kernels without a single kernel running on the NULL stream.  (Work on the caller's own NON-blocking streams is the caller's
+// to synchronise, as with any HIP API; modgpu.h says so.)
+struct PartsLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t after_callers_work = nullptr;
+};
+static PartsLane parts_lane(int logical)
 {
     static std::mutex mu;
-    static hipStream_t streams[kMaxDevices] = {};
-    if (logical < 0 || logical >= kMaxDevices) return nullptr;
+    static PartsLane lanes[kMaxDevices] = {};
+    if (logical < 0 || logical >= kMaxDevices) return PartsLane{};
     std::lock_guard<std::mutex> lock(mu);
-    if (!streams[logical] && hipStreamCreateWithFlags(&streams[logical], hipStreamNonBlocking) != hipSuccess) {
+    PartsLane &l = lanes[logical];
+    if (!l.stream && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) {
         (void)hipGetLastError();
-        streams[logical] = nullptr; // (the NULL stream still gives the right bytes)
+        l.stream = nullptr; // (the NULL stream still gives the right bytes, and its own ordering)
     }
-    return streams[logical];
+    if (l.stream && !l.after_callers_work && hipEventCreateWithFlags(&l.after_callers_work, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        l.after_callers_work = nullptr;
+    }
+    return l;
+}
+// The stream a device's parts are launched on, already waiting for whatever the caller queued on the NULL / blocking streams.
+static hipStream_t parts_stream_after_callers_work(int logical)
+{
+    const PartsLane l = parts_lane(logical);
+    if (!l.stream) return nullptr;
+    if (!l.after_callers_work || hipEventRecord(l.after_callers_work, nullptr) != hipSuccess || hipStreamWaitEvent(l.stream, l.after_callers_work, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr; // no way to order: fall back to the NULL stream itself, which is ordered by definition
+    }
+    return l.stream;
 }
 
 int modgpu_cycle_parts_device(void *const *dev_parts, const uint64_t *sizes, const int *devices, int n_parts, int32_t key)
@@ -943,6 +969,7 @@ int modgpu_cycle_parts_device(void *const *dev_parts, const uint64_t *sizes, con
         // every part its own Cycle from stream offset 0; the parts of one device go to it together (cycle_batch_impl)
         std::vector<char> taken((size_t)n_parts, 0);
         std::vector<int> started;
+        std::vector<hipStream_t> started_on;
         for (int i = 0; i < n_parts && rc == MODGPU_OK; ++i) {
             if (taken[(size_t)i]) continue;
             std::vector<void *> bufs;
@@ -955,14 +982,16 @@ int modgpu_cycle_parts_device(void *const *dev_parts, const uint64_t *sizes, con
                 }
             rc = select_device(devices[i]);
             if (rc == MODGPU_OK) {
+                hipStream_t st = parts_stream_after_callers_work(devices[i]);
                 started.push_back(devices[i]);
-                rc = cycle_batch_impl(bufs.data(), lens.data(), nullptr, (int)bufs.size(), key, parts_stream(devices[i]));
+                started_on.push_back(st);
+                rc = cycle_batch_impl(bufs.data(), lens.data(), nullptr, (int)bufs.size(), key, st);
             }
         }
         const std::string why = t_err;
-        for (int d : started) { // wait for what was started, also on the error path
-            if (select_device(d) != MODGPU_OK) continue;
-            hipError_t e = hipStreamSynchronize(parts_stream(d));
+        for (size_t k = 0; k < started.size(); ++k) { // wait for what was started, also on the error path
+            if (select_device(started[k]) != MODGPU_OK) continue;
+            hipError_t e = hipStreamSynchronize(started_on[k]);
             if (e != hipSuccess && rc == MODGPU_OK) rc = fail_hip(e, "hipStreamSynchronize");
         }
         if (rc != MODGPU_OK && !why.empty()) t_err = why;

@@ -18,6 +18,7 @@
 #include "scalar_path.h"
 
 #include <immintrin.h>
+#include <pthread.h>
 #include <sched.h>
 
 #include <algorithm>
@@ -293,8 +294,12 @@ struct HostPool {
     std::deque<std::shared_ptr<SpanCall>> requests;
     unsigned workers = 0, parked = 0;
 };
-HostPool *const g_pool = new HostPool; // never destroyed: parked workers wait on it for the life of the process
+HostPool *g_pool = new HostPool; // never destroyed: parked workers wait on it for the life of the process
 std::atomic<unsigned long long> g_pool_threads{0};
+// fork(): the child has the calling thread only -- the parked workers are gone, but the pool would still count them (and its
+// mutex may have been held by one of them at the moment of the fork): the child starts with a fresh, empty pool (ADVICE r4;
+// Python's multiprocessing forks by default).  The old pool is leaked on purpose.
+const int g_pool_atfork = ::pthread_atfork(nullptr, nullptr, [] { g_pool = new HostPool; });
 
 void pool_worker()
 {
@@ -324,6 +329,8 @@ unsigned modgpu_scalar_threads_for(uint64_t n)
     constexpr uint64_t kSpanMin = 2ull << 20;
     uint64_t t = std::min<uint64_t>(max_threads(), n / kSpanMin);
     if (const unsigned lim = cgroup_cpu_limit()) t = std::min<uint64_t>(t, lim);
+    if (t > 1) // ... nor more than the CALLING thread may run on right now: MODGPU_HOST_POLICY=fastest prices the loop with this number,
+        if (const size_t allowed = allowed_cpus().size()) t = std::min<uint64_t>(t, allowed); // and modgpu_scalar_cycle runs it with it
     return (unsigned)std::max<uint64_t>(t, 1);
 }
 unsigned long long modgpu_scalar_pool_threads() { return g_pool_threads.load(); }
@@ -392,6 +399,12 @@ void modgpu_scalar_cycle(uint8_t *buf, uint64_t n, int32_t key, uint64_t stream_
     }
     g_pool->cv.notify_all();
     call->help(false);
-    std::unique_lock<std::mutex> lock(call->mu);
-    call->cv.wait(lock, [&] { return call->finished == call->count; });
+    {
+        std::unique_lock<std::mutex> lock(call->mu);
+        call->cv.wait(lock, [&] { return call->finished == call->count; });
+    }
+    // entries of this call that no worker has picked up (all busy, or none could be started) are of no use to anybody now
+    std::lock_guard<std::mutex> lock(g_pool->mu);
+    auto &q = g_pool->requests;
+    q.erase(std::remove(q.begin(), q.end(), call), q.end());
 }

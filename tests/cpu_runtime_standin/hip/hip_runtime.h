@@ -59,6 +59,7 @@ hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags); // work queued on s after this waits for e's last record
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 
 // shim internals shared with standin_launch.cpp

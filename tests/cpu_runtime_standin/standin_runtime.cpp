@@ -162,6 +162,12 @@ hipError_t hipEventSynchronize(hipEvent_t e)
     e->cv.wait(lock, [e] { return !e->pending; });
     return hipSuccess;
 }
+static void run_wait_event(void *p) { (void)hipEventSynchronize(static_cast<hipEvent_t>(p)); }
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
+{
+    resolve(s)->push(run_wait_event, e);
+    return hipSuccess;
+}
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 {
     *ms = std::chrono::duration<float, std::milli>(b->at - a->at).count();

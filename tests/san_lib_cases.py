@@ -157,7 +157,7 @@ def test_staged_pipelines_and_routes(hooks):
     the staged route, pinned caller memory through both pinned routes, registered memory, placed memory."""
     assert M.host_tunables()["chunk_bytes"] == 1 << 20
     ck = M.host_chunking()
-    assert ck["ramp_bytes"] == 256 << 10 and ck["lanes"] == 2  # the 17 MiB case below takes the ramped plan, kernels on two shared lanes
+    assert ck["ramp_bytes"] == 256 << 10 and ck["lanes"] == 4  # the 17 MiB case below takes the ramped plan, kernels on four shared lanes
     big_off = (1 << 64) - 70000  # (a staged buffer's chunk positions are added to the offset: the sum must not wrap at 2^64)
     z = np.zeros((5 << 20) + 3, np.uint8)
     assert np.array_equal(M.cycle_host(z.copy(), M.KEY_PS3, stream_off=big_off), want(z, M.KEY_PS3, big_off))

@@ -1063,6 +1063,37 @@ print("CONFIG3_OK", checked)
 """
 
 
+def test_parts_device_runs_after_work_the_caller_queued_on_the_null_stream(gpu, oracle):
+    """modgpu_cycle_parts_device launches on a private non-blocking stream; work the caller queued just before on the
+    NULL stream (an asynchronous upload of the part, the usual producer) must still be ordered in front of the kernels.  A 1 GiB
+    asynchronous H2D copy from page-locked memory takes ~20 ms, the kernel 0.3 ms: without the ordering the kernel would cycle
+    the buffer's OLD contents and the copy would then overwrite the result with plaintext."""
+    import ctypes
+    import hip_rt  # tests/hip_rt.py
+    n = 1 << 30
+    pb = gpu.PinnedBuffer(n)
+    tile = oracle.splitmix_bytes(1 << 24, 31)
+    for off in range(0, n, tile.size):
+        pb.array[off:off + tile.size] = tile
+    d = gpu.DeviceBuffer(n, device=0)
+    d.upload(np.zeros(1 << 20, np.uint8))  # (old contents; also makes the device current and ready)
+    d.sync()
+    for rep in range(3):
+        rc = hip_rt.hip().hipMemcpyAsync(ctypes.c_void_p(d.ptr), ctypes.c_void_p(pb.ptr), ctypes.c_size_t(n), ctypes.c_int(1), ctypes.c_void_p(0))
+        assert rc == 0
+        gpu.cycle_parts_device([d], gpu.KEY_PS4)  # returns when its kernels have finished -- which must be after the copy
+        got = d.download(1 << 24, offset=(rep * 37 << 24) % n)
+        want = tile.copy()
+        oracle.cycle_at(want, gpu.KEY_PS4, (rep * 37 << 24) % n)
+        assert np.array_equal(got, want), rep
+        tail = d.download(4096, offset=n - 4096)
+        w = tile[-4096:].copy()
+        oracle.cycle_at(w, gpu.KEY_PS4, n - 4096)
+        assert np.array_equal(tail, w), rep
+    d.free()
+    pb.free()
+
+
 def test_config3_full_size_eight_resident_parts_on_aliased_devices(gpu):
     """BASELINE config 3 at its stated size -- 8 parts x 2^32 bytes, resident, part i on GPU i -- driven by
     one modgpu_cycle_parts_device call.  This box has one GPU (32 of its 288 GB hold the parts); the eight logical

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the multi-GPU path is a partition with no data-path collective.
+"""CPU, world_size 2 and 8 over gloo: the multi-GPU path is a partition with no data-path collective.
 The ranks here stand in for GPUs: each cycles the parts it owns with the PRODUCT's host loop
 (modgpu_cycle_scalar_host -- there is no GPU in this container) and the parent checks every part
 against the oracle.  Under test: round-robin part ownership, stream splitting by offset with
@@ -77,9 +77,11 @@ def _worker(rank, world, port, tmpdir):
 
 
 @pytest.mark.skipif(os.environ.get("MODGPU_REQUIRE_GPU", "0") not in ("", "0"), reason="MODGPU_REQUIRE_GPU forbids the host loop the CPU ranks use")
-def test_world2_gloo(tmp_path, oracle):
+@pytest.mark.parametrize("world", [2, 8])
+def test_world_n_gloo(tmp_path, oracle, world):
+    """world 2, and world 8 -- the node's GPU count, with more ranks than parts (5): three ranks own nothing and must still take
+    part in the reductions and the barrier; the split stream has eight spans."""
     import torch.multiprocessing as mp
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     sizes = [5000, 0, 70001, 4096, 33]
     for i, s in enumerate(sizes):

@@ -6,6 +6,7 @@
 // KNOWINGLY WRONG (B2 = 0 races the ticket hand-off: timing only); tools/tune_cycle marks such rows INVALID.
 // With every knob at its default a lab kernel is the product kernel's loop: tools/tune_cycle times both side by side.
 #pragma once
+#include <type_traits>
 #include "cycle_kernel_impl.h"
 
 constexpr uint32_t kTraceSlots = 64; // per workgroup: start, up to 62 trip ends, XCC id
@@ -258,10 +259,18 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
 // TK    = 1 (round 4; the PRODUCT's since then): the ticket is fetched at the START of a trip (in front of the load burst) and
 //         published in the same trip, so a workgroup is committed to one chunk fewer when the tickets run out (PREFIX = DEPTH + 1).
 //         TK = 0: round 3's timing (fetched behind the second barrier, published a trip later)
+// LSP   (round 5, one counter-guided experiment: profiles/r04_memside_counters.json has reads in flight at a third of what the
+//         workgroups could keep outstanding -- each has loads in flight for only ~1/3 of its 3.7 us trip).  Spreads the next chunk's
+//         U loads over the trip instead of issuing them as one burst behind the first barrier:
+//         1 = two half-bursts: U/2 loads at the trip's start, U/2 behind the keystream of word U/2 - 1 (both barriers kept);
+//         2 = the first U/2 words of chunk k+2 are issued at the END of trip k, behind its store burst and the ticket read (the
+//             buffer they land in has just been stored), the other U/2 behind trip k+1's first barrier as before.
+//         DEPTH 1, TK 1, no TSPLIT.
 template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int LAUX = AUX_NT, int B1 = 1, int B2 = 1,
-          int TSPLIT = 0, int TK = 1, int TLOOP = 0>
+          int TSPLIT = 0, int TK = 1, int TLOOP = 0, int LSP = 0>
 __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void lab_cycle_queue_kernel(LabQueueArgs la)
 {
+    static_assert(LSP == 0 || (DEPTH == 1 && TK == 1 && TSPLIT == 0 && TLOOP == 0 && U % 2 == 0), "LSP is an experiment on the product's loop shape");
     const CycleQueueArgs &a = la.q;
     static_assert(BLOCK % 256 == 0 && BLOCK <= 1024, "BLOCK is a whole number of 4096-byte tiles");
     static_assert(DEPTH >= 1 && DEPTH <= 3, "1..3 chunks of loads in flight");
@@ -386,6 +395,13 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
 #pragma unroll
         for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, LAUX);
     };
+    // LSP: words [U0, U1) of chunk g only
+    [[maybe_unused]] auto load_some = [&](u32x4(&d)[U], uint32_t g, auto u0, auto u1) {
+        locate(g, vl);
+        auto r = rsrc_at(g, vl);
+#pragma unroll
+        for (int u = decltype(u0)::value; u < decltype(u1)::value; ++u) d[u] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + u * SUB, 0, LAUX);
+    };
     // Lane 0's ticket traffic.  The returning atomic is a plain compiler-visible atomic, so the compiler counts it
     // in its own s_waitcnt vmcnt(N) bookkeeping and waits for the value only where it is published, a trip
     // later.  This needs the TU built with  -mllvm -amdgpu-atomic-optimizer-strategy=None : the default
@@ -397,18 +413,29 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
     const uint32_t q_next_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&q_next[0];
     const uint32_t one = 1u;
     // one trip: chunk g's words are in d; compute, publish last trip's ticket, barrier, fetch a ticket, store burst
-    auto process_store = [&](u32x4(&d)[U], uint32_t g, bool publish) {
+    auto process_store = [&](u32x4(&d)[U], uint32_t g, bool publish, auto &&mid) { // mid(): issued between words U/2 - 1 and U/2 (LSP 1)
         locate(g, vs);
         auto r = rsrc_at(g, vs);
         if constexpr (MODE == MODE_COPY) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) d[u] = ~d[u];
+            for (int u = 0; u < U / 2; ++u) d[u] = ~d[u];
+            mid();
+#pragma unroll
+            for (int u = U / 2; u < U; ++u) d[u] = ~d[u];
         } else {
             uint32_t s[U];
             states(g, vs, s);
             if (INLOOP && g - vs.lo >= n_full) { // a piece: its words only (wave-uniform branch)
 #pragma unroll
                 for (int u = 0; u < (U >> TSPLIT); ++u) d[u] = lab_cycle_word<ALG>(d[u], s[u]);
+            } else if constexpr (LSP == 1) {
+#pragma unroll
+                for (int u = 0; u < U / 2; ++u) d[u] = lab_cycle_word<ALG>(d[u], s[u]);
+                __builtin_amdgcn_sched_barrier(0);
+                mid();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = U / 2; u < U; ++u) d[u] = lab_cycle_word<ALG>(d[u], s[u]);
             } else {
 #pragma unroll
                 for (int u = 0; u < U; ++u) d[u] = lab_cycle_word<ALG>(d[u], s[u]);
@@ -480,8 +507,12 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
     bool publish = false; // the first trip has no ticket to publish yet
     if (active && cq[0] < limit_main) {
         u32x4 d[NB][U];
+        using W0 = std::integral_constant<int, 0>;
+        using WH = std::integral_constant<int, U / 2>;
+        using WU = std::integral_constant<int, U>;
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) load(d[i], cq[i]);
+        if constexpr (LSP == 2) load_some(d[DEPTH % NB], cq[DEPTH], W0{}, WH{}); // position 1's first half: nobody else will issue it
         bool finished = false;
         while (!finished) {
 #pragma unroll
@@ -491,9 +522,13 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
                     if (tid == 0) pending = __hip_atomic_fetch_add(a.queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     publish = true;
                 }
-                load(d[(p + DEPTH) % NB], cq[DEPTH]);
+                if constexpr (LSP == 0) load(d[(p + DEPTH) % NB], cq[DEPTH]);
+                else if constexpr (LSP == 1) load_some(d[(p + DEPTH) % NB], cq[DEPTH], W0{}, WH{});
+                else load_some(d[(p + DEPTH) % NB], cq[DEPTH], WH{}, WU{});
                 __builtin_amdgcn_sched_barrier(0);
-                process_store(d[p], cq[0], publish);
+                process_store(d[p], cq[0], publish, [&] {
+                    if constexpr (LSP == 1) load_some(d[(p + DEPTH) % NB], cq[DEPTH], WH{}, WU{});
+                });
 #pragma unroll
                 for (int i = 0; i < DEPTH; ++i) cq[i] = cq[i + 1];
                 cq[DEPTH] = publish ? take_published() : last_static;
@@ -502,6 +537,8 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
                     finished = true;
                     break;
                 }
+                // LSP 2: chunk k+2 is known now and the buffer it will land in (this trip's) has just been handed to the store burst
+                if constexpr (LSP == 2) load_some(d[p], cq[DEPTH], W0{}, WH{});
             }
         }
     }

@@ -21,6 +21,7 @@
 #include <dirent.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -313,15 +314,70 @@ static int series_main(Ctx &c, uint64_t n, int launches, Producer prod, int pre_
     return 0;
 }
 
+// ---- wake: what the chip's FIRST launch after an upload pays, and whether a one-wave kernel enqueued by the producer takes it away
+// (BENCH_r04: 411 MB 0.1941 ms as the first launch after the upload, 0.1259 ms for the launch right after).
+// Every trial: `idle_ms` of nothing (the shader engines go to sleep), then the part is uploaded the way bench.py does it
+// (modgpu_h2d, 64 MiB tiles, synchronous), then ONE modgpu_cycle_device launch timed by HIP events on its stream AND by two stamp
+// kernels' wall clocks.  Variants, interleaved:
+//   plain        nothing else                                       (what round 4's library does)
+//   at_start     a one-wave kernel on another stream when the upload STARTS (async; the engines have the whole upload to wake)
+//   each_tile    the same before every tile (an upload of seconds could let them fall asleep again)
+//   at_end       a one-wave kernel right after the last tile, not waited for
+//   waited       a one-wave kernel after the last tile, WAITED for, then the launch: the wake-up paid outside the timed launch --
+//                the floor any trick can reach; its own duration is the wake-up itself
+__global__ void nop_kernel(uint32_t *sink) { if (sink && threadIdx.x == 12345u) *sink = 1; }
+static int wake_main(Ctx &c, uint64_t n, int trials, int idle_ms)
+{
+    hipStream_t side;
+    CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    const char *names[] = {"plain", "at_start", "each_tile", "at_end", "waited"};
+    const int V = 5;
+    std::vector<std::vector<float>> ms(V), nop_us(V), next_ms(V);
+    auto nop = [&](hipStream_t st) { hipLaunchKernelGGL(nop_kernel, dim3(1), dim3(64), 0, st, c.sink); };
+    for (int t = 0; t < trials; ++t)
+        for (int v = 0; v < V; ++v) {
+            usleep(idle_ms * 1000);
+            if (v == 1) nop(side);
+            for (uint64_t off = 0; off < n; off += kTile) {
+                if (v == 2) nop(side);
+                MOD(modgpu_h2d(c.buf + off, c.pinned, std::min(kTile, n - off), 0));
+            }
+            float w = 0;
+            if (v == 3) nop(side);
+            if (v == 4) {
+                const auto t0 = std::chrono::steady_clock::now();
+                nop(side);
+                CHECK(hipStreamSynchronize(side));
+                w = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            }
+            ms[v].push_back(one_launch_ms(c, n));
+            next_ms[v].push_back(one_launch_ms(c, n)); // the launch right after (undoes the first): the size's own rate
+            nop_us[v].push_back(w);
+            CHECK(hipStreamSynchronize(side));
+        }
+    printf("== wake: %d trials per variant, interleaved; %d ms idle, upload of %.0f MiB through modgpu_h2d, then ONE launch (HIP events)\n", trials, idle_ms, n / 1048576.0);
+    printf("   %-10s  %28s  %28s  %s\n", "variant", "first launch: median / min / max ms", "next launch: median ms", "GB/s (median first)   frac of 8 TB/s");
+    for (int v = 0; v < V; ++v) {
+        auto med = [](std::vector<float> x) { std::sort(x.begin(), x.end()); return x[x.size() / 2]; };
+        const float m = med(ms[v]);
+        printf("   %-10s  %10.4f / %7.4f / %7.4f  %28.4f  %10.1f  %.4f", names[v], m, *std::min_element(ms[v].begin(), ms[v].end()), *std::max_element(ms[v].begin(), ms[v].end()),
+               med(next_ms[v]), 2.0 * n / (m * 1e-3) / 1e9, 2.0 * n / (m * 1e-3) / 8e12);
+        if (v == 4) printf("   (the waited-for one-wave kernel: median %.1f us by the host's clock)", med(nop_us[v]));
+        printf("\n");
+    }
+    CHECK(hipStreamDestroy(side));
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) {
-        fprintf(stderr, "usage: first_pass series [bytes] [launches] [producer] [idle_ms] | first_pass first\n");
+        fprintf(stderr, "usage: first_pass series [bytes] [launches] [producer] [idle_ms] | first_pass first | first_pass wake [bytes] [trials] [idle_ms]\n");
         return 2;
     }
-    const bool series = strcmp(argv[1], "series") == 0;
+    const bool series = strcmp(argv[1], "series") == 0, wake = strcmp(argv[1], "wake") == 0;
     Ctx c;
-    c.cap = series && argc > 2 ? strtoull(argv[2], nullptr, 0) : 1ull << 32;
+    c.cap = (series || wake) && argc > 2 ? strtoull(argv[2], nullptr, 0) : 1ull << 32;
     CHECK(hipSetDevice(0));
     CHECK(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
     CHECK(hipMalloc(&c.buf, c.cap));
@@ -332,7 +388,8 @@ int main(int argc, char **argv)
     for (uint64_t i = 0; i < kTile; ++i) c.pinned[i] = (uint8_t)(i * 131 + 7);
     CHECK(hipDeviceSynchronize());
     int rc;
-    if (series) rc = series_main(c, c.cap, argc > 3 ? atoi(argv[3]) : 16, argc > 4 ? parse_producer(argv[4]) : P_H2D, argc > 5 ? atoi(argv[5]) : 0);
+    if (wake) rc = wake_main(c, c.cap, argc > 3 ? atoi(argv[3]) : 7, argc > 4 ? atoi(argv[4]) : 1500);
+    else if (series) rc = series_main(c, c.cap, argc > 3 ? atoi(argv[3]) : 16, argc > 4 ? parse_producer(argv[4]) : P_H2D, argc > 5 ? atoi(argv[5]) : 0);
     else rc = first_main(c);
     modgpu_path_stats_t st;
     MOD(modgpu_path_stats(&st, 0));

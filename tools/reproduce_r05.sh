@@ -28,5 +28,18 @@ pcie)         # profiles/r05_pcie_route_*.json: rocprofv3 under 
     find $D -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_pcie_route_config4_kernel_stats.csv
     find $D -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_pcie_route_config4_kernel_trace.csv
     rm -rf $D ;;
-*) echo "usage: tools/reproduce_r05.sh build | pcie [tag]" ;;
+grid)         # profiles/r05_pcie_grid.txt: workgroups of a launch across PCIe, lanes, and how a staged stream is cut
+    timeout -k 10 420 python3 tools/sweep_pcie_grid.py grid > $O/r05_sweep_grid.txt
+    timeout -k 10 300 python3 tools/sweep_pcie_grid.py cut > $O/r05_sweep_cut.txt ;;
+wake)         # profiles/r05_first_launch.txt: the chip's first launch after an upload
+    timeout -k 10 200 tools/first_pass wake 411000000 9 1500 > $O/r05_wake_411MB.txt
+    timeout -k 10 200 tools/first_pass wake 4294967296 5 1500 > $O/r05_wake_4GiB.txt
+    timeout -k 10 200 tools/first_pass wake 411000000 9 100 > $O/r05_wake_411MB_idle100ms.txt ;;
+lsp)          # profiles/r05_lsp.txt: the next chunk's loads spread over the trip, every row validated
+    for n in 4294967296 411000000; do
+      TUNE_ONLY="LSP|PRODUCT modgpu_cycle_queue" timeout -k 10 400 tools/tune_cycle $n 9 > $O/r05_lsp_$n.txt
+    done ;;
+crossover)    # profiles/r05_small_call_crossover.txt: both engines per call (the table MODGPU_HOST_POLICY=fastest decides by)
+    modulate_amd/bin/modbench --hostcall > $O/r05_hostcall.txt ;;
+*) echo "usage: tools/reproduce_r05.sh build | pcie [tag] | grid | wake | lsp | crossover" ;;
 esac

@@ -50,11 +50,11 @@ template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = 16, int SYNC
 }
 
 // ALG: 2 = the shipped keystream sequence (canonicalising carry out of the fold, 3 instructions per byte), 1 = round 2's (4 per byte)
-template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int SAUX = 16, int LAUX = 2, int B1 = 1, int B2 = 1, int ALG = 2, int TSPLIT = 0, int TK = 1, int TLOOP = 0>
+template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int SAUX = 16, int LAUX = 2, int B1 = 1, int B2 = 1, int ALG = 2, int TSPLIT = 0, int TK = 1, int TLOOP = 0, int LSP = 0>
 void launch_queue(const LabArgs &a, uint32_t grid, hipStream_t st)
 {
     // (the kernel takes a table of parts: one buffer planned as a CycleArgs is a table of one)
-    hipLaunchKernelGGL((lab_cycle_queue_kernel<U, BLOCK, ALG, SAUX, TRACE, DEPTH, MODE, LAUX, B1, B2, TSPLIT, TK, TLOOP>), dim3(grid), dim3(BLOCK), 0, st,
+    hipLaunchKernelGGL((lab_cycle_queue_kernel<U, BLOCK, ALG, SAUX, TRACE, DEPTH, MODE, LAUX, B1, B2, TSPLIT, TK, TLOOP, LSP>), dim3(grid), dim3(BLOCK), 0, st,
                        lab_queue_args_of(a, (uint32_t)U * BLOCK * 16));
 }
 // the kernels the product ships, instantiated from the product header itself
@@ -561,6 +561,40 @@ int main(int argc, char **argv)
         // the pieces in a second, cold loop behind the trip loop (the trip loop itself as the product's)
         for (uint32_t t : {g / 4, g / 2, g, 3 * g / 2, 2 * g, 3 * g}) add_tail("TLOOP halves in a cold second loop", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 1, 0, 1>, t);
         for (uint32_t t : {g / 4, g / 2, g, 2 * g}) add_tail("TLOOP quarters in a cold second loop", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 2, 0, 1>, t);
+    }
+    // ---- round 5, ONE counter-guided experiment: the next chunk's loads spread over the trip (LSP, cycle_kernel_lab.h)
+    for (uint32_t g : {200u, 256u}) {
+        char b_[160];
+        snprintf(b_, sizeof b_, "queue   LSP 1: loads as two half-bursts (2 at the start, 2 behind word 1)   grid= %u", autogrid(65536, g));
+        vs.push_back({0, b_, launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 1>, 65536, autogrid(65536, g), {}});
+        snprintf(b_, sizeof b_, "queue   LSP 2: 2 words of chunk k+2 behind trip k's store burst            grid= %u", autogrid(65536, g));
+        vs.push_back({0, b_, launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 2>, 65536, autogrid(65536, g), {}});
+        snprintf(b_, sizeof b_, "queue   LSP 0: the product's single burst (lab form)                        grid= %u", autogrid(65536, g));
+        vs.push_back({0, b_, launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 65536, autogrid(65536, g), {}});
+    }
+    vs.push_back({0, "queue   LSP 1 COPY-ONLY                                                          grid= 200", launch_queue<4, 1024, 0, 1, MODE_COPY, 18, 2, 1, 1, 2, 0, 1, 0, 1>, 65536, autogrid(65536, 200), {}});
+    vs.push_back({0, "queue   LSP 2 COPY-ONLY                                                          grid= 200", launch_queue<4, 1024, 0, 1, MODE_COPY, 18, 2, 1, 1, 2, 0, 1, 0, 2>, 65536, autogrid(65536, 200), {}});
+    vs.push_back({0, "queue   LSP 0 COPY-ONLY                                                          grid= 200", launch_queue<4, 1024, 0, 1, MODE_COPY, 18>, 65536, autogrid(65536, 200), {}});
+    // TUNE_ONLY="token|token": keep the variants whose name contains one of the tokens (an experiment's rows interleaved with each
+    // other only, in a fraction of the time the whole table takes)
+    if (const char *only = getenv("TUNE_ONLY")) {
+        std::vector<std::string> toks;
+        std::string cur;
+        for (const char *c = only;; ++c) {
+            if (*c == '|' || *c == 0) {
+                if (!cur.empty()) toks.push_back(cur);
+                cur.clear();
+                if (*c == 0) break;
+            } else cur.push_back(*c);
+        }
+        std::vector<Variant> keep;
+        for (auto &v : vs)
+            for (auto &t : toks)
+                if (v.name.find(t) != std::string::npos) {
+                    keep.push_back(v);
+                    break;
+                }
+        vs.swap(keep);
     }
     LabArgs a{};
     CHECK(hipMalloc(&a.queue, 64));
