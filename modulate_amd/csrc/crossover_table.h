@@ -1,7 +1,7 @@
 // crossover_table.h -- what MODGPU_HOST_POLICY=fastest decides by: the two engines' measured rates for a caller-owned HOST
 // buffer on the node class this library is tuned on (MI355X behind PCIe gen 5 x16, 2 x EPYC 9575F), from
-// profiles/r04_small_call_crossover.txt and r04_staged_midsize.txt (bin/modbench --hostcall, tools/sweep_midsize_host.py; re-measure
-// there and edit here for another host).
+// profiles/r05_small_call_crossover.txt (kernel route) and r04_small_call_crossover.txt (host loop) -- bin/modbench --hostcall; re-measure
+// there and edit here for another host.
 // Payload GB/s, one call, warm.  Not used by the default policy (offload), which only has the size threshold.
 #pragma once
 #include <cstdint>
@@ -10,8 +10,8 @@ namespace crossover {
 
 // kernel route, PAGEABLE caller memory (staged: memcpy -> pinned slot -> kernel across PCIe -> memcpy back)
 struct Point { uint64_t bytes; double gbps; };
-constexpr Point kKernelPageable[] = {
-    {4ull << 20, 16.6}, {8ull << 20, 22.1}, {16ull << 20, 30.0}, {32ull << 20, 31.4}, {64ull << 20, 35.5}, {128ull << 20, 39.6}, {256ull << 20, 41.7}, {1024ull << 20, 44.1}, {4096ull << 20, 45.0},
+constexpr Point kKernelPageable[] = { // round 5 (32 workgroups per short launch across the link, ~64 chunks of >= 1 MiB): profiles/r05_small_call_crossover.txt
+    {4ull << 20, 22.4}, {8ull << 20, 32.4}, {16ull << 20, 35.4}, {32ull << 20, 39.1}, {64ull << 20, 40.7}, {128ull << 20, 43.5}, {256ull << 20, 45.6}, {1024ull << 20, 47.2}, {4096ull << 20, 48.0},
 };
 // kernel route, PAGE-LOCKED caller memory (modgpu_host_alloc / _register): one kernel across PCIe where the pages lie
 constexpr double kKernelPinnedGbps = 50.0;     // profiles/r02_sweep_pinned_routes.txt

@@ -226,20 +226,32 @@ int HostCall()
     if( gpu && !crossed ) std::printf( "   the host loop is ahead at every size of this table\n" );
     // part-sized buffers: the kernel route (staged through pinned slots, 8 pipelines) against the host loop on ONE thread
     // (2 MiB pieces, each below the size from which the loop spreads over threads) and on its threads
-    std::printf( "== part-sized pageable buffers: GB/s of payload, best of 3\n" );
+    std::printf( "== part-sized pageable buffers: GB/s of payload; kernel route best of 5-10 calls (all sizes first), host loop best of 3\n" );
     std::printf( "   %10s  %14s  %18s  %18s\n", "MiB", "kernel route", "host loop 1 thread", "host loop threads" );
-    for( uint64_t n : { 4ull << 20, 8ull << 20, 16ull << 20, 32ull << 20, 64ull << 20, 256ull << 20, 1ull << 30 } )
+    // (the kernel route of every size first, the host loop afterwards: sixteen host-loop threads that have just used up the
+    //  control group's CPU quota leave the staging pipelines' copy threads throttled for the next measurement -- round 5 saw the
+    //  kernel column 25-40 % low when the two were interleaved per size)
+    const uint64_t partSizes[] = { 4ull << 20, 8ull << 20, 16ull << 20, 32ull << 20, 64ull << 20, 256ull << 20, 1ull << 30 };
+    auto best = []( int reps, auto&& run ) { double b = 1e30; for( int i = 0; i < reps; ++i ) { const double t0 = Now(); run(); b = std::min( b, Now() - t0 ); } return b; };
+    std::vector< double > kernelSeconds;
+    for( uint64_t n : partSizes )
     {
         std::vector< unsigned char > buf( n, 0x3C );
-        auto best = []( auto&& run ) { double b = 1e30; for( int i = 0; i < 3; ++i ) { const double t0 = Now(); run(); b = std::min( b, Now() - t0 ); } return b; };
         double g = -1;
         if( gpu )
         {
-            TRY( modgpu_cycle_host( buf.data(), n, kKey, 0, 0 ) );
-            g = best( [ & ] { (void)modgpu_cycle_host( buf.data(), n, kKey, 0, 0 ); } );
+            for( int i = 0; i < 2; ++i ) TRY( modgpu_cycle_host( buf.data(), n, kKey, 0, 0 ) );
+            g = best( n <= ( 64ull << 20 ) ? 10 : 5, [ & ] { (void)modgpu_cycle_host( buf.data(), n, kKey, 0, 0 ); } );
         }
-        const double h1 = best( [ & ] { for( uint64_t off = 0; off < n; off += 2ull << 20 ) (void)modgpu_cycle_scalar_host( buf.data() + off, std::min< uint64_t >( 2ull << 20, n - off ), kKey, off ); } );
-        const double ht = best( [ & ] { (void)modgpu_cycle_scalar_host( buf.data(), n, kKey, 0 ); } );
+        kernelSeconds.push_back( g );
+    }
+    size_t row = 0;
+    for( uint64_t n : partSizes )
+    {
+        std::vector< unsigned char > buf( n, 0x3C );
+        const double g = kernelSeconds[ row++ ];
+        const double h1 = best( 3, [ & ] { for( uint64_t off = 0; off < n; off += 2ull << 20 ) (void)modgpu_cycle_scalar_host( buf.data() + off, std::min< uint64_t >( 2ull << 20, n - off ), kKey, off ); } );
+        const double ht = best( 3, [ & ] { (void)modgpu_cycle_scalar_host( buf.data(), n, kKey, 0 ); } );
         std::printf( "   %10llu  %14.1f  %18.1f  %18.1f\n", (unsigned long long)( n >> 20 ), gpu ? n / g / 1e9 : -1.0, n / h1 / 1e9, n / ht / 1e9 );
     }
     std::printf( "== host loop throughput by body (in place, warm; one thread below 4 MiB, MODGPU_HOST_THREADS / all cores above)\n" );

@@ -659,6 +659,14 @@ void prepare_device()
         a.base_head = a.base_body = a.base_tail = 1;
         a.stride_mul2 = 2;
         (void)modgpu_launch_cycle(a, CYCLE_SMALL, 1, st);
+        // ... and one empty launch of the work-queue kernel (no parts, no chunks; its ticket pair is the zeroed scratch, not a ring
+        // line): the runtime resolves a kernel function the first time it is launched, ~40 us on the host that HIP events around a
+        // caller's first large launch would count (bench.py's first_pass.part_411MB: 0.1698 ms against 0.1295 for the second).
+        if (hipMemsetAsync(scratch, 0, 4096, st) == hipSuccess) {
+            CycleQueueArgs q{};
+            q.queue = reinterpret_cast<uint32_t *>(scratch);
+            (void)modgpu_launch_cycle_queue(q, 1, st);
+        }
         (void)hipStreamSynchronize(st);
     }
     (void)hipGetLastError();
@@ -1241,11 +1249,44 @@ int modgpu_free(void *dev_ptr, int device)
     });
 }
 
+// The chip's shader engines go to sleep within a fraction of a second without kernels -- an upload keeps only the DMA engines
+// busy -- and the first launch after that pays their wake-up: ~15 us on a 411 MB launch, ~40 us for a one-wave kernel by the host's
+// clock (profiles/r05_first_launch.txt; BENCH_r04 had the chip's first 411 MB launch after the upload at 0.529 of peak, the next
+// at 0.816).  A part that is being uploaded is about to be cycled, and this library is the one doing the upload: when a copy
+// STARTS, an empty launch (zero words, one workgroup) goes to a stream of the library's own that nobody waits for, so the engines
+// wake while the DMA engine works.  Measured: first launch after a 1.5 s pause + upload 0.1420 -> 0.1262 ms at 411 MB, which is
+// the size's own rate (0.1261).  Best effort; costs the caller one asynchronous launch call per copy of 1 MiB or more.
+static void wake_shader_engines(int logical)
+{
+    static std::mutex mu;
+    static hipStream_t streams[kMaxDevices] = {};
+    if (logical < 0 || logical >= kMaxDevices) return;
+    hipStream_t st;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!streams[logical] && hipStreamCreateWithFlags(&streams[logical], hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            streams[logical] = nullptr;
+            return;
+        }
+        st = streams[logical];
+    }
+    CycleArgs a{}; // no head, no words, no tail: the one workgroup finds nothing to do
+    a.base_head = a.base_body = a.base_tail = 1;
+    a.stride_mul2 = 2;
+    (void)modgpu_launch_cycle(a, CYCLE_SMALL, 1, st);
+    (void)hipGetLastError();
+}
+
 int modgpu_h2d(void *dev_dst, const void *host_src, uint64_t n, int device)
 {
     return guarded([&]() -> int {
         DeviceScope scope(device);
         if (scope.rc) return scope.rc;
+        if (n >= (1ull << 20)) {
+            int logical = device;
+            if (logical >= 0 || hipGetDevice(&logical) == hipSuccess) wake_shader_engines(logical);
+        }
         if (n) HIP_TRY(hipMemcpy(dev_dst, host_src, n, hipMemcpyHostToDevice));
         return MODGPU_OK;
     });

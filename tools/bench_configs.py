@@ -54,10 +54,10 @@ def main():
     # ---- host-buffer path (PCIe-inclusive): modgpu_cycle_host on pageable memory
     M.cycle_host(np.zeros(1 << 20, np.uint8), M.KEY_PS4)  # create the staging context
     hp = {}
-    for n in (4096, 256 << 10, 64 << 20, 1 << 30, 1 << 32) if "host" in sections else ():
+    for n in (4096, 256 << 10, 16 << 20, 64 << 20, 256 << 20, 1 << 30, 1 << 32) if "host" in sections else ():
         buf = rng.integers(0, 256, size=min(n, 1 << 26), dtype=np.uint8)
         buf = np.resize(buf, n)
-        reps = 200 if n <= (256 << 10) else (5 if n <= (64 << 20) else 3)
+        reps = 200 if n <= (256 << 10) else (8 if n <= (256 << 20) else 3)
         M.cycle_host(buf, M.KEY_PS4)  # warm: staging slots for this size, page faults
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -81,6 +81,32 @@ def main():
         hpp[str(n)] = {"seconds_per_call": round(dt, 6), "GBps_payload": round(n / dt / 1e9, 3)}
         pb.free()
     res["host_path_pinned"] = hpp
+    if "host" in sections:
+        # The roofline of everything above: host-resident data is bound by the PCIe link, which every byte crosses once in each
+        # direction.  peak = what this node's link carries in both directions at once, measured here by the DMA
+        # engines (tools/ubench_pcie_bidir) and by the best the kernel itself has been seen to do in place on page-locked memory
+        # (the kernel beats the DMA engines at this); beside it the spec of PCIe gen 5 x16.
+        import re
+        import subprocess
+        dma = None
+        try:
+            out = subprocess.run([os.path.join(ROOT, "tools", "ubench_pcie_bidir")], capture_output=True, text=True, timeout=120).stdout
+            m = re.search(r"both ways:\s+([0-9.]+) GB/s", out)
+            dma = float(m.group(1)) if m else None
+            one_way = [float(x) for x in re.findall(r"only\s*:\s+([0-9.]+) GB/s", out)]
+        except (OSError, subprocess.SubprocessError):
+            one_way = []
+        kernel_peak = max(v["GBps_payload"] for v in hpp.values())
+        peak = max(kernel_peak, dma or 0.0)
+        res["roofline_pcie"] = {
+            "bound": "pcie", "unit": "GB/s of payload = GB/s in EACH direction of the link at once",
+            "peak": round(peak, 2), "peak_source": "best of: one kernel in place on page-locked memory (this run), DMA engines both ways at once (tools/ubench_pcie_bidir)",
+            "dma_both_ways_per_direction": dma, "dma_one_way": one_way, "spec_per_direction": 64.0,
+            "achieved": {"page_locked_in_place": {k: v["GBps_payload"] for k, v in hpp.items()},
+                         "pageable_staged": {k: v["GBps_payload"] for k, v in hp.items() if int(k) >= (1 << 20)}},
+            "frac": {"page_locked_in_place": {k: round(v["GBps_payload"] / peak, 4) for k, v in hpp.items()},
+                     "pageable_staged": {k: round(v["GBps_payload"] / peak, 4) for k, v in hp.items() if int(k) >= (1 << 20)}},
+        }
 
     # ---- config 1: 4 KiB framed blob, decrypt (plumbing)
     body = rng.integers(0, 256, size=4092, dtype=np.uint8)

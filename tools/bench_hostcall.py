@@ -10,6 +10,7 @@ CHILD = r'''
 import sys, time, numpy as np
 sys.path.insert(0, %r)
 import modulate_amd as M
+M.use_testing_flavour()  # the staging knobs set through the environment below exist in libmodgpu_testing.so only (round 5)
 for n in (64, 4096, 65536, 262144, 524288, 1 << 20, 2 << 20):
     buf = np.random.default_rng(1).integers(0, 256, size=n, dtype=np.uint8)
     for _ in range(20): M.cycle_host(buf, M.KEY_PS4)

@@ -317,7 +317,7 @@ static int series_main(Ctx &c, uint64_t n, int launches, Producer prod, int pre_
 // ---- wake: what the chip's FIRST launch after an upload pays, and whether a one-wave kernel enqueued by the producer takes it away
 // (BENCH_r04: 411 MB 0.1941 ms as the first launch after the upload, 0.1259 ms for the launch right after).
 // Every trial: `idle_ms` of nothing (the shader engines go to sleep), then the part is uploaded the way bench.py does it
-// (modgpu_h2d, 64 MiB tiles, synchronous), then ONE modgpu_cycle_device launch timed by HIP events on its stream AND by two stamp
+// (64 MiB tiles, synchronous hipMemcpy -- what modgpu_h2d was until round 5), then ONE modgpu_cycle_device launch timed by HIP events on its stream AND by two stamp
 // kernels' wall clocks.  Variants, interleaved:
 //   plain        nothing else                                       (what round 4's library does)
 //   at_start     a one-wave kernel on another stream when the upload STARTS (async; the engines have the whole upload to wake)
@@ -330,8 +330,8 @@ static int wake_main(Ctx &c, uint64_t n, int trials, int idle_ms)
 {
     hipStream_t side;
     CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    const char *names[] = {"plain", "at_start", "each_tile", "at_end", "waited"};
-    const int V = 5;
+    const char *names[] = {"plain", "at_start", "each_tile", "at_end", "waited", "library"};
+    const int V = 6; // "library": the upload through modgpu_h2d, which (since round 5) does each_tile itself; the others upload with hipMemcpy
     std::vector<std::vector<float>> ms(V), nop_us(V), next_ms(V);
     auto nop = [&](hipStream_t st) { hipLaunchKernelGGL(nop_kernel, dim3(1), dim3(64), 0, st, c.sink); };
     for (int t = 0; t < trials; ++t)
@@ -340,7 +340,8 @@ static int wake_main(Ctx &c, uint64_t n, int trials, int idle_ms)
             if (v == 1) nop(side);
             for (uint64_t off = 0; off < n; off += kTile) {
                 if (v == 2) nop(side);
-                MOD(modgpu_h2d(c.buf + off, c.pinned, std::min(kTile, n - off), 0));
+                if (v == 5) MOD(modgpu_h2d(c.buf + off, c.pinned, std::min(kTile, n - off), 0));
+                else CHECK(hipMemcpy(c.buf + off, c.pinned, std::min(kTile, n - off), hipMemcpyHostToDevice));
             }
             float w = 0;
             if (v == 3) nop(side);
@@ -355,7 +356,7 @@ static int wake_main(Ctx &c, uint64_t n, int trials, int idle_ms)
             nop_us[v].push_back(w);
             CHECK(hipStreamSynchronize(side));
         }
-    printf("== wake: %d trials per variant, interleaved; %d ms idle, upload of %.0f MiB through modgpu_h2d, then ONE launch (HIP events)\n", trials, idle_ms, n / 1048576.0);
+    printf("== wake: %d trials per variant, interleaved; %d ms idle, upload of %.0f MiB in 64 MiB tiles, then ONE launch (HIP events)\n", trials, idle_ms, n / 1048576.0);
     printf("   %-10s  %28s  %28s  %s\n", "variant", "first launch: median / min / max ms", "next launch: median ms", "GB/s (median first)   frac of 8 TB/s");
     for (int v = 0; v < V; ++v) {
         auto med = [](std::vector<float> x) { std::sort(x.begin(), x.end()); return x[x.size() / 2]; };

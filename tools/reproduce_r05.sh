@@ -39,7 +39,12 @@ lsp)          # profiles/r05_lsp.txt: the next chunk's loads spread over the tri
     for n in 4294967296 411000000; do
       TUNE_ONLY="LSP|PRODUCT modgpu_cycle_queue" timeout -k 10 400 tools/tune_cycle $n 9 > $O/r05_lsp_$n.txt
     done ;;
+lspcounters)  # profiles/r05_lsp_counters.json: reads in flight and fabric read latency of the LSP variants beside the product (one --pmc pass)
+    D=$O/lspc; rm -rf $D; mkdir -p $D
+    timeout -k 10 240 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_CYCLE_sum --output-format csv -d $D/pass1 -- tools/ubench_queue_rw 4294967296 200 2 > $D/pass1.log 2>&1
+    timeout -k 10 120 tools/ubench_queue_rw 4294967296 200 8 > $D/rates.txt 2>&1
+    python3 tools/summarize_memside.py $D > $O/r05_lsp_counters.json ;;
 crossover)    # profiles/r05_small_call_crossover.txt: both engines per call (the table MODGPU_HOST_POLICY=fastest decides by)
     modulate_amd/bin/modbench --hostcall > $O/r05_hostcall.txt ;;
-*) echo "usage: tools/reproduce_r05.sh build | pcie [tag] | grid | wake | lsp | crossover" ;;
+*) echo "usage: tools/reproduce_r05.sh build | pcie [tag] | grid | wake | lsp | lspcounters | crossover" ;;
 esac

@@ -16,6 +16,9 @@ def label(kernel):
         return {"0": "read_only", "1": "write_only", "2": "copy"}[m.group(1)]
     if "modgpu_cycle_queue_kernel" in kernel:
         return "product"
+    m = re.search(r"lab_cycle_queue_kernel<.*, (\d)>\(", kernel)  # the last template argument is LSP (tools/cycle_kernel_lab.h)
+    if m:
+        return "lab_lsp_%s" % m.group(1)
     return None
 
 
@@ -45,6 +48,8 @@ def main():
             d["avg_read_latency_l2_cycles"] = round(k.get("TCC_EA0_RDREQ_LEVEL_sum", 0) / k["TCC_EA0_RDREQ_sum"], 1)
         if k.get("TCC_EA0_WRREQ_sum"):
             d["avg_write_latency_l2_cycles"] = round(k.get("TCC_EA0_WRREQ_LEVEL_sum", 0) / k["TCC_EA0_WRREQ_sum"], 1)
+        if k.get("TCC_EA0_RDREQ_LEVEL_sum") and k.get("TCC_CYCLE_sum"):  # TCC_CYCLE_sum adds up the 128 channels' cycles
+            d["reads_in_flight_chip_wide"] = round(k["TCC_EA0_RDREQ_LEVEL_sum"] / (k["TCC_CYCLE_sum"] / 128.0))
         cyc = k.get("TCC_CYCLE_sum") or k.get("TCC_BUSY_sum")
         if cyc:
             for c in ("TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum", "TCC_EA0_WRREQ_STALL_sum", "TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum", "TCC_TAG_STALL_sum",

@@ -9,6 +9,7 @@ CHILD = r'''
 import sys, time, numpy as np
 sys.path.insert(0, %r)
 import modulate_amd as M
+M.use_testing_flavour()  # the staging knobs set through the environment below exist in libmodgpu_testing.so only (round 5)
 for n in (64 << 20, 1 << 30, 1 << 32):
     buf = np.empty(n, np.uint8); buf[:] = 7
     M.cycle_host(buf, M.KEY_PS4)            # warm: staging allocation, page faults

@@ -7,6 +7,8 @@
 // Round 4: the fourth row is the PRODUCT kernel itself (modgpu_cycle_queue_kernel<4, 1024> from the product header), so that one
 // `rocprofv3 --pmc` pass over this program reads the memory-side counters of all four under the same conditions
 // (tools/memside_counters.sh, profiles/r04_memside_counters.json).
+// Round 5: two more rows, the lab kernel at the product's settings with the next chunk's loads SPREAD over the trip (LSP 1 / 2,
+// tools/cycle_kernel_lab.h), so that the same counter pass says what that does to the reads in flight (profiles/r05_lsp.txt).
 // Build: make -C tools ubench_queue_rw
 // Run:   tools/ubench_queue_rw [bytes=4294967296] [grid=200] [rounds=8]
 #include <hip/hip_runtime.h>
@@ -15,7 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "cycle_kernel_impl.h"
+#include "cycle_kernel_lab.h" // (includes the product header; the lab kernel only for round 5's LSP rows)
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 enum { READ = 0, WRITE = 1, COPY = 2, FULL = 3 };
 constexpr int U = 4, BLOCK = 1024;
@@ -116,8 +118,8 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    const char *names[4] = {"read-only ", "write-only", "copy r+w  ", "PRODUCT   "};
-    std::vector<float> ms[4];
+    const char *names[6] = {"read-only ", "write-only", "copy r+w  ", "PRODUCT   ", "LAB LSP 1 ", "LAB LSP 2 "};
+    std::vector<float> ms[6];
     // the product kernel's table of one part (the buffer is chunk-aligned: no lead, no edges)
     CycleQueueArgs qa{};
     qa.queue = queue + 32; // a line of its own
@@ -126,14 +128,17 @@ int main(int argc, char **argv)
     qa.part[0].end = n / 16 * 16;
     qa.part[0].base_body = qa.part[0].base_head = qa.part[0].base_tail = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
     for (int k = 1; k <= kCycleBatchMax; ++k) qa.start[k] = (uint32_t)((qa.part[0].end + CHUNK - 1) / CHUNK);
+    const LabQueueArgs lqa{qa, nullptr, 0};
     for (int r = 0; r < rounds; ++r)
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < 6; ++m) {
             CHECK(hipEventRecord(e0, st));
             for (int k = 0; k < 2; ++k) {
                 if (m == READ) hipLaunchKernelGGL(rw_kernel<READ>, dim3(grid), dim3(BLOCK), 0, st, buf, n, queue, sink);
                 else if (m == WRITE) hipLaunchKernelGGL(rw_kernel<WRITE>, dim3(grid), dim3(BLOCK), 0, st, buf, n, queue, sink);
                 else if (m == COPY) hipLaunchKernelGGL(rw_kernel<COPY>, dim3(grid), dim3(BLOCK), 0, st, buf, n, queue, sink);
-                else hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, qa);
+                else if (m == FULL) hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, qa);
+                else if (m == 4) hipLaunchKernelGGL((lab_cycle_queue_kernel<U, BLOCK, 2, 18, 0, 1, MODE_FULL, 2, 1, 1, 0, 1, 0, 1>), dim3(grid), dim3(BLOCK), 0, st, lqa);
+                else hipLaunchKernelGGL((lab_cycle_queue_kernel<U, BLOCK, 2, 18, 0, 1, MODE_FULL, 2, 1, 1, 0, 1, 0, 2>), dim3(grid), dim3(BLOCK), 0, st, lqa);
             }
             CHECK(hipEventRecord(e1, st));
             CHECK(hipEventSynchronize(e1));
@@ -143,7 +148,7 @@ int main(int argc, char **argv)
         }
     CHECK(hipGetLastError());
     printf("bytes=%llu grid=%u, work-queue schedule, 64 KiB chunks (GB/s of HBM traffic: n for read-only / write-only, 2n for copy)\n", (unsigned long long)n, grid);
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < 6; ++m) {
         std::sort(ms[m].begin(), ms[m].end());
         const double traffic = (m >= COPY ? 2.0 : 1.0) * n;
         printf("  %s  median %.4f ms -> %7.1f GB/s   best %7.1f\n", names[m], ms[m][ms[m].size() / 2], traffic / ms[m][ms[m].size() / 2] / 1e6,
