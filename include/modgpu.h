@@ -119,7 +119,7 @@ const char *modgpu_last_error(void);
  * launch two executable graphs instantiated from the same capture concurrently.  Both replay the same node, scratch
  * included: the tickets of the two runs would interleave and bytes would come out wrong WITHOUT an error.  Capture again
  * for every concurrent user.
- * Captured large launches draw their scratch from a grow-only pool of 1 023 lines per device that is never handed out
+ * Captured large launches draw their scratch from a grow-only pool of 1 024 lines per device that is never handed out
  * again (a graph may be replayed at any time).  A process that keeps re-capturing exhausts it; captures beyond that -- and a
  * capture that is the device's very first large launch -- take the static streaming shape, which needs no scratch and is
  * correct but ~7 % slower at 4 GiB.  modgpu_queue_stats (modgpu_testing.h) counts both. */
@@ -213,13 +213,14 @@ int modgpu_cycle_parts_device(void *const *dev_parts, const uint64_t *sizes, con
  * keystream position stream_off (0 = a part's own Cycle). */
 
 /* Whole file src_path -> dst_path (created / truncated).  The two may name the same file, by any
- * spelling (compared by device and inode): it is then cycled in place. */
+ * spelling (compared by device and inode): it is then cycled in place.
+ * All three file routes share one rule for a GPU that is LOST AFTER THE CALL HAS BEGUN: the source still holds every byte (a
+ * destination file is written piece by piece, each only when it is finished, also in place), so the pieces that have not
+ * arrived are read again and done by the library's host loop -- unless MODGPU_REQUIRE_GPU=1; modgpu_path_stats().midcall_rescues
+ * counts such calls.  Without a usable GPU at the start they fail like every other kernel entry point. */
 int modgpu_cycle_file(const char *src_path, const char *dst_path, int32_t key, uint64_t stream_off, int device);
 
-/* n bytes at byte offset file_off of `path` -> host_dst[0..n).  If the GPU is lost after the call has begun, the pieces that have
- * not arrived in host_dst are read from the file again and done by the host loop (the file still holds every byte, whatever
- * kind of memory host_dst is) -- unless MODGPU_REQUIRE_GPU=1; counted in modgpu_path_stats().midcall_rescues.  Without a
- * usable GPU at the start the call fails like every other kernel entry point. */
+/* n bytes at byte offset file_off of `path` -> host_dst[0..n) (any kind of memory; the rule above holds whatever host_dst is). */
 int modgpu_cycle_file_to_host(const char *path, uint64_t file_off, uint8_t *host_dst, uint64_t n, int32_t key,
                               uint64_t stream_off, int device);
 
@@ -272,7 +273,7 @@ typedef struct modgpu_path_stats {
     uint64_t auto_fallbacks; /* modgpu_cycle_auto_host calls that ended on the host loop because the GPU could not serve them */
     uint64_t auto_small;     /* modgpu_cycle_auto_host calls served by the host loop because n < MODGPU_MIN_GPU_BYTES */
     uint64_t auto_policy_host; /* modgpu_cycle_auto_host calls of n >= MODGPU_MIN_GPU_BYTES that MODGPU_HOST_POLICY=fastest kept on the host loop */
-    uint64_t midcall_rescues;       /* calls (modgpu_cycle_auto_host, modgpu_cycle_file_to_host) whose GPU was lost AFTER the call had begun and
+    uint64_t midcall_rescues;       /* calls (modgpu_cycle_auto_host, the modgpu_cycle_file* routes) whose GPU was lost AFTER the call had begun and
                                        that the host loop finished: counted in gpu_calls AND -- for _auto_ -- in auto_fallbacks */
     uint64_t midcall_rescued_bytes; /* bytes of those calls the host loop did (in scalar_bytes, not in gpu_bytes) */
 } modgpu_path_stats_t;

@@ -874,7 +874,9 @@ int modgpu_cycle_file(const char *src_path, const char *dst_path, int32_t key, u
         Endpoint src, dst;
         src.fd = in_place ? out.fd : in.fd;
         dst.fd = out.fd;
-        return stream_impl(src, dst, (uint64_t)st_in.st_size, key, stream_off, device, false, nullptr);
+        // (a GPU lost after the call has begun: the source file still holds every byte -- in place, too, since a piece is written
+        //  only when it is finished -- so the host loop does the pieces that have not been written; see modgpu_cycle_file_to_host)
+        return stream_impl(src, dst, (uint64_t)st_in.st_size, key, stream_off, device, !gpu_required(), nullptr);
     });
 }
 
@@ -909,7 +911,7 @@ int modgpu_cycle_host_to_file(const uint8_t *host_src, uint64_t n, const char *p
         src.mem = const_cast<uint8_t *>(host_src); // only read from
         src.pinned = host_range_pinned(host_src, n);
         dst.fd = out.fd;
-        return stream_impl(src, dst, n, key, stream_off, device, false, nullptr);
+        return stream_impl(src, dst, n, key, stream_off, device, !gpu_required(), nullptr); // (host_src is never modified: lost pieces are done from it again)
     });
 }
 

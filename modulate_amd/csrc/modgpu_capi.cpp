@@ -548,7 +548,7 @@ int launch_queue(void *const *bufs, const uint64_t *sizes, const uint64_t *offs,
     // ... at the clock the chip normally runs at.  While power management holds the shader clock low (the first ~10 ms after
     // load onset) the kernel is bound by its arithmetic instead, and the CUs left idle are worth more than the tidy memory
     // pattern: they get a HELPER workgroup each, which measures the clock when it starts and joins the ticket queue only
-    // while it is below MODGPU_HELPER_BELOW_MHZ (default 1850; cycle_kernel_impl.h; profiles/r03_first_pass.txt, r03_tune_dvfs.txt).
+    // while it is below MODGPU_HELPER_BELOW_MHZ (default: 77 % of the device's peak shader clock, 1 848 MHz on MI355X; cycle_kernel_impl.h; profiles/r03_first_pass.txt, r03_tune_dvfs.txt).
     uint64_t cap = 0, helpers = 0;
     queue_grid(total, large_grid(), &cap, &helpers);
     const uint64_t main_groups = std::max<uint64_t>(1, std::min<uint64_t>(total, cap));
@@ -659,13 +659,30 @@ void prepare_device()
         a.base_head = a.base_body = a.base_tail = 1;
         a.stride_mul2 = 2;
         (void)modgpu_launch_cycle(a, CYCLE_SMALL, 1, st);
-        // ... and one empty launch of the work-queue kernel (no parts, no chunks; its ticket pair is the zeroed scratch, not a ring
-        // line): the runtime resolves a kernel function the first time it is launched, ~40 us on the host that HIP events around a
-        // caller's first large launch would count (bench.py's first_pass.part_411MB: 0.1698 ms against 0.1295 for the second).
-        if (hipMemsetAsync(scratch, 0, 4096, st) == hipSuccess) {
-            CycleQueueArgs q{};
-            q.queue = reinterpret_cast<uint32_t *>(scratch);
-            (void)modgpu_launch_cycle_queue(q, 1, st);
+        // ... and two REAL launches of the work-queue kernel over a scratch buffer (two 64 KiB parts sharing a launch: ring line,
+        // ticket traffic, sign-off word and all).  A process's first real work-queue launch costs 15-35 us more than its later
+        // ones -- the runtime resolves the kernel function, the ring's host-visible sign-off words are touched for the first time --
+        // and HIP events around a caller's first large launch count that: a fresh process's first 411 MB launch after an upload
+        // took 0.143-0.148 ms without this against 0.128-0.133 with it, 0.126-0.128 being the size's steady rate
+        // (profiles/r05_first_launch.txt; an EMPTY launch of the same kernel, even on the full grid, bought only 0.139).
+        // Not counted in modgpu_path_stats / modgpu_queue_stats, not reported by modgpu_last_launch: it is nobody's launch.
+        {
+            const modgpu_launch_info_t keep = t_last_launch;
+            uint8_t *big = nullptr;
+            if (hipMalloc(reinterpret_cast<void **>(&big), 3u << 16) == hipSuccess) {
+                void *parts[2] = {big, big + (1u << 16)};
+                const uint64_t sizes[2] = {1u << 16, 1u << 16};
+                for (int k = 0; k < 2; ++k)
+                    if (launch_queue(parts, sizes, nullptr, 2, /*key_res=*/1, st) == MODGPU_OK) {
+                        g_stats.gpu_launches.fetch_sub(1, std::memory_order_relaxed);
+                        g_queue_eager.fetch_sub(1, std::memory_order_relaxed);
+                        g_batch_launches.fetch_sub(1, std::memory_order_relaxed);
+                        g_batch_parts.fetch_sub(2, std::memory_order_relaxed);
+                    }
+                (void)hipStreamSynchronize(st);
+                (void)hipFree(big);
+            }
+            t_last_launch = keep;
         }
         (void)hipStreamSynchronize(st);
     }

@@ -144,6 +144,34 @@ if not strict:
                 assert after["midcall_rescues"] == before["midcall_rescues"] + 1 and after["auto_fallbacks"] == before["auto_fallbacks"]
                 if pinned_dst:
                     pb.free()
+        # ---- the other two file routes: host -> file (SaveArk's part cipher; the source memory is never modified) and file -> file,
+        # to another file and in place (a piece is written only when it is finished, so the unwritten ones are still plaintext)
+        out_path = path + ".out"
+        for pinned_src in (False, True):
+            if pinned_src:
+                pb = M.PinnedBuffer(n)
+                pb.array[:] = pt
+                src = pb.array
+            else:
+                src = pt.copy()
+            for piece, stage in ((0, M.STAGE_LAUNCH), (M.INJECT_PIECE_MIDDLE, M.STAGE_SYNC), (M.INJECT_PIECE_LAST, M.STAGE_DRAIN)):
+                before = M.path_stats()
+                M.debug_inject_failure_at(piece, stage)
+                M.cycle_host_to_file(src, out_path, M.KEY_PS4)
+                assert not M.debug_injection_armed() and M.path_stats()["midcall_rescues"] == before["midcall_rescues"] + 1
+                assert np.array_equal(np.fromfile(out_path, dtype=np.uint8), want), ("host -> file", pinned_src, piece, stage)
+                assert np.array_equal(src, pt)
+            if pinned_src:
+                pb.free()
+        for in_place in (False, True):
+            for piece, stage in ((0, M.STAGE_FILL), (M.INJECT_PIECE_MIDDLE, M.STAGE_SYNC), (M.INJECT_PIECE_LAST, M.STAGE_AFTER_DRAIN)):
+                pt.tofile(path)
+                before = M.path_stats()
+                M.debug_inject_failure_at(piece, stage)
+                M.cycle_file(path, path if in_place else out_path, M.KEY_PS4)
+                assert not M.debug_injection_armed() and M.path_stats()["midcall_rescues"] == before["midcall_rescues"] + 1
+                assert np.array_equal(np.fromfile(path if in_place else out_path, dtype=np.uint8), want), ("file -> file", in_place, piece, stage)
+        os.unlink(out_path)
     finally:
         os.unlink(path)
 print("MIDCALL_OK", strict)

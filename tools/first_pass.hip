@@ -326,23 +326,55 @@ static int series_main(Ctx &c, uint64_t n, int launches, Producer prod, int pre_
 //   waited       a one-wave kernel after the last tile, WAITED for, then the launch: the wake-up paid outside the timed launch --
 //                the floor any trick can reach; its own duration is the wake-up itself
 __global__ void nop_kernel(uint32_t *sink) { if (sink && threadIdx.x == 12345u) *sink = 1; }
+// one word per 64 KiB of a buffer: the address translations of its pages are walked before the first real launch needs them
+__global__ void touch_kernel(const uint32_t *p, uint64_t blocks, uint32_t *sink)
+{
+    uint32_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < blocks; i += (uint64_t)gridDim.x * blockDim.x) acc ^= p[i * 16384];
+    if (acc == 0x9E3779B9u) *sink = acc;
+}
 static int wake_main(Ctx &c, uint64_t n, int trials, int idle_ms)
 {
     hipStream_t side;
     CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    const char *names[] = {"plain", "at_start", "each_tile", "at_end", "waited", "library"};
-    const int V = 6; // "library": the upload through modgpu_h2d, which (since round 5) does each_tile itself; the others upload with hipMemcpy
+    const char *names[] = {"plain", "at_start", "each_tile", "at_end", "waited", "library", "fresh", "fresh_touch", "fresh_2nd", "null_stream"};
+    const int V = 10; // "null_stream": as "library", the launch on the legacy NULL stream (where bench.py's first_pass launches) // "library": the upload through modgpu_h2d, which (since round 5) does each_tile itself; the others upload with hipMemcpy.
+    // "fresh": as "library", into a buffer allocated for this trial (hipMalloc) -- what bench.py's part is: memory no shader has touched
+    // yet, so the first launch also walks cold page tables; "fresh_touch": the same, and a side-stream kernel reads one word per 64 KiB
+    // of it after the upload (not waited for); "fresh_2nd": fresh, and the number reported is the SECOND launch's (for comparison)
     std::vector<std::vector<float>> ms(V), nop_us(V), next_ms(V);
     auto nop = [&](hipStream_t st) { hipLaunchKernelGGL(nop_kernel, dim3(1), dim3(64), 0, st, c.sink); };
+    // WAKE_ONLY=<variant index>: that variant alone (with trials = 1: the PROCESS's first large launch, what bench.py's first_pass times)
+    const int only = getenv("WAKE_ONLY") ? atoi(getenv("WAKE_ONLY")) : -1;
+    if (only >= 0) { // the part as bench.py has it: from modgpu_alloc, which also prepares the device (code object, ring, both kernels resolved)
+        void *p = nullptr;
+        MOD(modgpu_alloc(&p, n, 0));
+        c.buf = (uint8_t *)p;
+        if (getenv("WAKE_WARM")) { // a REAL work-queue launch (two 64 KiB parts share one: ring line, sign-off word and all) before anything is timed
+            void *parts[2] = {c.buf, c.buf + (1 << 20)};
+            uint64_t sizes[2] = {65536, 65536};
+            for (int k = 0; k < 2; ++k) MOD(modgpu_cycle_batch_device(parts, sizes, nullptr, 2, KEY, 0, c.st));
+            CHECK(hipStreamSynchronize(c.st));
+        }
+    }
     for (int t = 0; t < trials; ++t)
         for (int v = 0; v < V; ++v) {
+            if (only >= 0 && v != only) {
+                ms[v].push_back(0), next_ms[v].push_back(0), nop_us[v].push_back(0);
+                continue;
+            }
             usleep(idle_ms * 1000);
+            uint8_t *const keep = c.buf;
+            if (v >= 6 && v <= 8) CHECK(hipMalloc(&c.buf, n));
+            hipStream_t const keep_st = c.st;
+            if (v == 9) c.st = nullptr;
             if (v == 1) nop(side);
             for (uint64_t off = 0; off < n; off += kTile) {
                 if (v == 2) nop(side);
-                if (v == 5) MOD(modgpu_h2d(c.buf + off, c.pinned, std::min(kTile, n - off), 0));
+                if (v >= 5) MOD(modgpu_h2d(c.buf + off, c.pinned, std::min(kTile, n - off), 0));
                 else CHECK(hipMemcpy(c.buf + off, c.pinned, std::min(kTile, n - off), hipMemcpyHostToDevice));
             }
+            if (v == 7) hipLaunchKernelGGL(touch_kernel, dim3(64), dim3(256), 0, side, (const uint32_t *)c.buf, n / 65536, c.sink);
             float w = 0;
             if (v == 3) nop(side);
             if (v == 4) {
@@ -351,10 +383,16 @@ static int wake_main(Ctx &c, uint64_t n, int trials, int idle_ms)
                 CHECK(hipStreamSynchronize(side));
                 w = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
             }
-            ms[v].push_back(one_launch_ms(c, n));
-            next_ms[v].push_back(one_launch_ms(c, n)); // the launch right after (undoes the first): the size's own rate
+            const float first = one_launch_ms(c, n), second = one_launch_ms(c, n); // the launch right after undoes the first: the size's own rate
+            ms[v].push_back(v == 8 ? second : first);
+            next_ms[v].push_back(second);
             nop_us[v].push_back(w);
             CHECK(hipStreamSynchronize(side));
+            c.st = keep_st;
+            if (v >= 6 && v <= 8) {
+                CHECK(hipFree(c.buf));
+                c.buf = keep;
+            }
         }
     printf("== wake: %d trials per variant, interleaved; %d ms idle, upload of %.0f MiB in 64 MiB tiles, then ONE launch (HIP events)\n", trials, idle_ms, n / 1048576.0);
     printf("   %-10s  %28s  %28s  %s\n", "variant", "first launch: median / min / max ms", "next launch: median ms", "GB/s (median first)   frac of 8 TB/s");
