@@ -40,7 +40,9 @@
  * relied on, and a call made with an explicit device leaves the calling thread's current HIP
  * device as it found it.  Host-buffer calls to the same device run side by side, each on staging slots of its own (a call
  * that finds too few free takes fewer pipelines; one that finds none waits for a release).  The library keeps parked worker
- * threads (per device for the staging pipelines, one pool for the host loop): started on first use, never joined.
+ * threads (for the staging pipelines per device and per NUMA node a caller's pages have been found on -- slots and workers sit
+ * on the node of the pages they copy, only the GPU crosses the socket link; one pool for the host loop): started on first use,
+ * never joined.
  *
  * Environment (each read once, when first needed) -- these ten and no others (tests/test_capi_cpu.py compares this list with the
  * strings of the built library):

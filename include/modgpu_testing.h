@@ -82,8 +82,9 @@ void modgpu_host_trace(int enable);
 int modgpu_host_trace_read(modgpu_host_trace_event_t *out, int cap);
 /* The staging contexts' bookkeeping since load: out[0] = worker threads started (they park between calls and are never
  * joined), out[1] = pipelines run by workers, out[2] = calls that had to wait for a slot, out[3] = host-buffer calls that began
- * while another was in flight (any device), out[4] = slots per device. */
-void modgpu_host_pool_stats(uint64_t out[5]);
+ * while another was in flight (any device), out[4] = slots per staging set, out[5] = calls that took the staging set of ANOTHER NUMA
+ * node than the GPU's because the caller's pageable pages live there (slots allocated on that node, workers bound to it). */
+void modgpu_host_pool_stats(uint64_t out[6]);
 
 /* What shapes the host loop's threading in this process: out[0] = most threads per call (MODGPU_HOST_THREADS as latched),
  * out[1] = the control group's CPU limit (cpu.max; 0 = none known), out[2] = CPUs in the calling thread's affinity mask,
@@ -143,6 +144,10 @@ void modgpu_debug_set_launch(int variant, uint32_t grid_cap);
 enum { MODGPU_TUNABLE_ZEROCOPY_BYTES = 0, MODGPU_TUNABLE_RING = 1, MODGPU_TUNABLE_SPLIT = 2, MODGPU_TUNABLE_CHUNK_MIN_BYTES = 3,
        MODGPU_TUNABLE_RAMP_BYTES = 4, MODGPU_TUNABLE_LANES = 5, MODGPU_TUNABLE_NTCOPY = 6 };
 void modgpu_debug_set_host_tunable(int which, uint64_t value);
+
+/* The NUMA node the library believes its GPUs hang off (-1 = unknown, -2 = ask sysfs, the default).  Lets a one-node machine
+ * exercise the staging set of "another node than the GPU's" (own placed slots, workers bound to the node). */
+void modgpu_debug_set_gpu_node(int node);
 
 /* Workgroups of a launch that works across PCIe on page-locked host memory (0 = the product's rule).  Measurement only
  * (tools/sweep_pcie_grid.py). */

@@ -114,6 +114,7 @@ DEBUG_EXPORTS = {
     "modgpu_debug_set_helpers": (None, [_int]),
     "modgpu_debug_set_batch": (None, [_int]),
     "modgpu_debug_set_pcie_grid": (None, [ctypes.c_uint32]),
+    "modgpu_debug_set_gpu_node": (None, [_int]),
     "modgpu_debug_set_host_tunable": (None, [_int, _u64]),
     "modgpu_debug_inject_failures": (None, [_int]),
     "modgpu_debug_inject_failure_at": (None, [ctypes.c_int64, _int]),
@@ -272,6 +273,11 @@ def debug_set_host_tunable(name, value):
     _debug_lib().modgpu_debug_set_host_tunable(HOST_TUNABLES[name], int(value))
 
 
+def debug_set_gpu_node(node=-2):
+    """Testing flavour: the NUMA node the library believes its GPUs hang off (-2 = ask sysfs)."""
+    _debug_lib().modgpu_debug_set_gpu_node(node)
+
+
 def debug_set_pcie_grid(cap=0):
     """Measurement hook: workgroups of a launch across PCIe (0 = the product's rule)."""
     _debug_lib().modgpu_debug_set_pcie_grid(cap)
@@ -387,10 +393,10 @@ def host_trace_read():
 
 
 def host_pool_stats():
-    out = (_u64 * 5)()
+    out = (_u64 * 6)()
     lib().modgpu_host_pool_stats(out)
     return {"workers_started": int(out[0]), "pipelines_run_by_workers": int(out[1]), "slot_waits": int(out[2]),
-            "calls_overlapped": int(out[3]), "slots_per_device": int(out[4])}
+            "calls_overlapped": int(out[3]), "slots_per_device": int(out[4]), "calls_on_another_nodes_set": int(out[5])}
 
 
 def kernel_source_hash():

@@ -30,6 +30,7 @@
 //       pread / pwrite schedule with the cipher skipped (I/O only) and the cipher with the I/O skipped (GPU only).
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <immintrin.h>
@@ -366,7 +367,7 @@ int HostTrace()
             std::printf( "   %4llu MiB x %d caller%s: %7.3f ms  %6.1f GB/s\n", (unsigned long long)mib, callers, callers > 1 ? "s" : " ", best * 1e3, callers * (double)n / best / 1e9 );
         }
     }
-    uint64_t ps[ 5 ];
+    uint64_t ps[ 6 ];
     modgpu_host_pool_stats( ps );
     std::printf( "   staging pool: %llu worker threads started in this process, %llu pipelines run by them, %llu waits for a slot, %llu calls began while another was in flight\n",
                  (unsigned long long)ps[ 0 ], (unsigned long long)ps[ 1 ], (unsigned long long)ps[ 2 ], (unsigned long long)ps[ 3 ] );
@@ -374,6 +375,7 @@ int HostTrace()
 }
 
 // ---- --route: one host-buffer route, R calls, every launch listed (to be joined with a rocprofv3 kernel trace) -------------------
+uint64_t gRouteOffset = 4; // --offset K: the buffer starts K bytes behind a page boundary (the reference's callers pass buf + 4)
 int Route( const std::string& kind, uint64_t mib, int reps )
 {
     if( modgpu_device_count() < 1 ) { std::printf( "no HIP device\n" ); return 1; }
@@ -382,8 +384,8 @@ int Route( const std::string& kind, uint64_t mib, int reps )
     void* mem = nullptr;
     std::vector< unsigned char > pageable;
     if( pinned ) TRY( modgpu_host_alloc( &mem, n + 64 ) );
-    else { pageable.assign( n + 64, 0 ); mem = pageable.data(); }
-    unsigned char* buf = static_cast< unsigned char* >( mem ) + 4; // the reference's callers pass buf + 4
+    else { pageable.assign( n + 8192, 0 ); mem = reinterpret_cast< void* >( ( reinterpret_cast< uintptr_t >( pageable.data() ) + 4095 ) & ~uintptr_t( 4095 ) ); }
+    unsigned char* buf = static_cast< unsigned char* >( mem ) + ( pinned ? 4 : gRouteOffset );
     const std::vector< unsigned char > tile = Tile( 1u << 20, 777 );
     for( uint64_t off = 0; off < n; off += tile.size() ) std::memcpy( buf + off, tile.data(), std::min< uint64_t >( tile.size(), n - off ) );
     uint64_t tun[ 4 ], chk[ 4 ];
@@ -392,6 +394,13 @@ int Route( const std::string& kind, uint64_t mib, int reps )
     std::printf( "route %s  bytes %llu  reps %d  pinned_as_seen_by_the_library %d  pipes<=%llu slot<=%lluMiB split~%llu chunk>=%lluMiB ramp %lluKiB lanes %llu\n", kind.c_str(),
                  (unsigned long long)n, reps, modgpu_host_is_pinned( buf, n ), (unsigned long long)tun[ 0 ], (unsigned long long)( tun[ 1 ] >> 20 ),
                  (unsigned long long)chk[ 0 ], (unsigned long long)( chk[ 1 ] >> 20 ), (unsigned long long)( chk[ 2 ] >> 10 ), (unsigned long long)chk[ 3 ] );
+    { // where this process happens to live: the staged route's copies are CPU work, and which NUMA node the caller's pages are on decides their rate
+        unsigned cpu = 0, node = 0;
+        (void)::syscall( SYS_getcpu, &cpu, &node, nullptr );
+        int pageNode = -1;
+        (void)::syscall( SYS_get_mempolicy, &pageNode, nullptr, 0, buf + n / 2, 3 /* MPOL_F_NODE | MPOL_F_ADDR */ );
+        std::printf( "placement: calling thread on cpu %u of NUMA node %u; the buffer's middle page on node %d; the GPU hangs off node %d\n", cpu, node, pageNode, modgpu_device_numa_node( 0 ) );
+    }
     modgpu_host_trace( 1 ); // from the first call on: the launch list below must hold EVERY launch the profiler sees
     for( int i = 0; i < 2; ++i ) TRY( modgpu_cycle_host( buf, n, kKey, 0, 0 ) ); // slots, workers, page faults
     std::vector< double > walls;
@@ -406,6 +415,11 @@ int Route( const std::string& kind, uint64_t mib, int reps )
     std::sort( sorted.begin(), sorted.end() );
     std::printf( "calls (after 2 untimed): best %.3f ms = %.2f GB/s, median %.3f ms = %.2f GB/s of payload (each byte crosses the link twice)\n", sorted.front() * 1e3,
                  n / sorted.front() / 1e9, sorted[ sorted.size() / 2 ] * 1e3, n / sorted[ sorted.size() / 2 ] / 1e9 );
+    {
+        uint64_t ps[ 6 ];
+        modgpu_host_pool_stats( ps );
+        std::printf( "staging: %llu of this process's calls took the slots and workers of ANOTHER NUMA node than the GPU's (the caller's pages live there)\n", (unsigned long long)ps[ 5 ] );
+    }
     for( size_t r = 0; r < walls.size(); ++r ) std::printf( "call %zu wall_us %.1f\n", r + 2, walls[ r ] * 1e6 );
     std::vector< modgpu_host_trace_event_t > ev( (size_t)modgpu_host_trace_read( nullptr, 0 ) );
     modgpu_host_trace_read( ev.data(), (int)ev.size() );
@@ -671,6 +685,7 @@ int main( int argc, char** argv )
         else if( a == "--trace" ) trace = true;
         else if( a == "--route" ) { mode = "route"; route = next(); }
         else if( a == "--mib" ) routeMib = std::strtoull( next(), nullptr, 0 );
+        else if( a == "--offset" ) gRouteOffset = std::strtoull( next(), nullptr, 0 ) & 4095;
         else if( a == "--reps" ) routeReps = std::max( 1, std::atoi( next() ) );
         else if( a == "--alloc" ) { mode = "alloc"; partBytes = 3291444381ull; nParts = 8; }
         else if( a == "--numa" ) { mode = "numa"; partBytes = 1ull << 30; }

@@ -31,6 +31,7 @@
 // every step of a call with a timestamp; bin/modbench --hostcall --trace prints the timeline.
 #include <fcntl.h>
 #include <pthread.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -51,6 +52,7 @@
 
 #include "../../include/modgpu_testing.h"
 #include "modgpu_internal.h"
+#include "numa_place.h"
 #include "scalar_path.h"
 
 namespace modgpu {
@@ -170,12 +172,22 @@ struct Staging {
     bool busy[kSlots] = {};                     // under mu
     std::deque<std::shared_ptr<Call>> requests; // under mu: one entry per pipeline a call would like a worker for
     int workers = 0, parked = 0;                // under mu
+    int node = -1; // NUMA node this set's slots and workers live on; -1: next to the GPU (where the runtime puts page-locked memory)
+    bool placed[kSlots] = {}; // the slot's pinned buffer is our own placed mapping (numa::reserve + hipHostRegister), not hipHostMalloc's
 };
-Staging *g_staging = new Staging[kMaxDevices];
+// A device has one staging context per NUMA node a caller's pages can be on (round 5, profiles/r05_staged_numa.txt).  The staged
+// route is two CPU copies of every byte, and a copy whose SOURCE is on the other socket runs at 6-12 GB/s per thread instead of 28:
+// with the slots next to the GPU (where hipHostMalloc puts them) and the caller's pages on the other socket, either the copy in or
+// the copy out reads remotely whichever socket the workers run on -- pageable 64 MiB fell from 44 to 20-35 GB/s, in about half of
+// all processes on a two-socket node.  So a call whose pages live on another node than the GPU takes THAT node's set: slots
+// allocated there, workers bound there; both copies stay inside one socket and only the GPU crosses to the other -- which costs
+// it nothing (one kernel across PCIe on the other socket's memory runs at the same 50 GB/s, profiles/r03_numa.txt).
+constexpr int kNodeSets = 5; // set 0: next to the GPU (also: node unknown, file endpoints); sets 1..4: NUMA nodes 0..3
+Staging *g_staging = new Staging[kMaxDevices * kNodeSets];
 // fork(): the child has neither the parked workers nor a usable HIP context; it starts with fresh, empty staging contexts (the
 // old ones, whose mutexes a vanished thread may hold, are leaked on purpose).  ADVICE r4.
-const int g_staging_atfork = ::pthread_atfork(nullptr, nullptr, [] { g_staging = new Staging[kMaxDevices]; });
-std::atomic<uint64_t> g_pool_spawned{0}, g_pool_tasks{0}, g_slot_waits{0}, g_calls_in_flight{0}, g_calls_overlapped{0};
+const int g_staging_atfork = ::pthread_atfork(nullptr, nullptr, [] { g_staging = new Staging[kMaxDevices * kNodeSets]; });
+std::atomic<uint64_t> g_pool_spawned{0}, g_pool_tasks{0}, g_slot_waits{0}, g_calls_in_flight{0}, g_calls_overlapped{0}, g_node_set_calls{0};
 
 // Slots a call owns, given back (and waiters woken) when the call ends, whichever way.
 struct SlotLease {
@@ -230,10 +242,28 @@ int staging_reserve(Staging &s, const std::vector<int> &ids, uint64_t need, bool
         if (!s.stream[i]) HIP_TRY(hipStreamCreateWithFlags(&s.stream[i], hipStreamNonBlocking));
         if (!s.event[i]) HIP_TRY(hipEventCreateWithFlags(&s.event[i], hipEventDisableTiming));
         if (want_pinned && s.pinned_cap[i] < need) {
-            if (s.pinned[i]) HIP_TRY(hipHostFree(s.pinned[i]));
+            if (s.pinned[i]) {
+                if (s.placed[i]) {
+                    HIP_TRY(hipHostUnregister(s.pinned[i]));
+                    numa::release(s.pinned[i], s.pinned_cap[i]);
+                } else HIP_TRY(hipHostFree(s.pinned[i]));
+            }
             s.pinned[i] = nullptr;
             s.pinned_cap[i] = 0;
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.pinned[i]), need, hipHostMallocPortable | hipHostMallocMapped));
+            s.placed[i] = false;
+            if (s.node >= 0) { // this set's slots live on a named node: our own mapping, bound, touched, then page-locked in place
+                void *p = numa::reserve(need);
+                if (p && numa::prefer_node(p, need, s.node) == 0) {
+                    numa::prefault(p, need, 1, "/sys", -1);
+                    if (hipHostRegister(p, need, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess) {
+                        s.pinned[i] = static_cast<uint8_t *>(p);
+                        s.placed[i] = true;
+                        p = nullptr;
+                    } else (void)hipGetLastError();
+                }
+                if (p) numa::release(p, need); // (no placement to be had: the runtime's own allocation below)
+            }
+            if (!s.pinned[i]) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.pinned[i]), need, hipHostMallocPortable | hipHostMallocMapped));
             s.pinned_cap[i] = need;
         }
         if (want_dev && s.dev_cap[i] < need) {
@@ -327,6 +357,9 @@ struct Job {
     std::unique_ptr<std::atomic<uint8_t>[]> done; // per piece: its result is in the destination, whole
     std::vector<hipStream_t> lanes; // kernels across PCIe are queued on these in launch order (empty: each on its slot's stream)
     std::atomic<uint64_t> launched{0};
+    int copy_node = -1; // NUMA node the caller's pages live on (-1: unknown, or no pageable memory endpoint): picks the staging set (g_staging)
+    cpu_set_t caller_mask; // the calling thread's affinity mask: a worker is never put on a CPU the caller may not use
+    bool have_mask = false;
     Job(const Endpoint &s, const Endpoint &d, uint64_t n_, uint64_t chunk_, int32_t key_, uint64_t off_) : src(s), dst(d), n(n_), chunk(chunk_), key(key_), stream_off(off_) {}
     void set_plan(std::vector<Piece> p)
     {
@@ -510,9 +543,11 @@ struct Call {
 };
 
 // A parked worker: bound to its GPU's NUMA node and HIP device once, then serves whatever calls post.
-void worker_main(Staging *s, int logical, int phys)
+void worker_main(Staging *s, int logical, int phys, cpu_set_t allowed, bool have_allowed)
 {
-    run_near_device(logical); // a staging worker's memcpys run on the socket its GPU hangs off
+    // a staging worker's copies run where its set's slots are: next to the GPU, or on the node the set was made for
+    if (s->node >= 0 && have_allowed) (void)numa::move_to_node(s->node, &allowed, sizeof allowed);
+    else if (s->node < 0) run_near_device(logical);
     (void)hipSetDevice(phys); // HIP's current device is per thread
     std::unique_lock<std::mutex> lock(s->mu);
     for (;;) {
@@ -539,7 +574,7 @@ void post_to_workers(Staging &s, const std::shared_ptr<Call> &call, int extra, i
         const int short_of = (int)s.requests.size() - s.parked;
         for (int k = 0; k < short_of && s.workers < kMaxPipes - 1; ++k) {
             try {
-                std::thread(worker_main, &s, logical, call->phys).detach();
+                std::thread(worker_main, &s, logical, call->phys, call->job.caller_mask, call->job.have_mask).detach();
                 ++s.workers;
                 g_pool_spawned.fetch_add(1, std::memory_order_relaxed);
             } catch (...) {
@@ -612,7 +647,26 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     const bool in_place = src.mem && src.mem == dst.mem;
     if (identity && in_place) return MODGPU_OK;
     if (dev >= kMaxDevices) return fail(MODGPU_ERR_INVALID, "device index beyond staging table");
-    Staging &s = g_staging[dev];
+    const bool src_direct = src.mem && src.pinned, dst_direct = dst.mem && dst.pinned;
+    // which of the device's staging sets: the one on the node the caller's PAGEABLE pages live on, if that is not the GPU's own
+    int copy_node = -1;
+    cpu_set_t caller_mask;
+    bool have_mask = false;
+    if (numa::enabled() && n > kZeroCopyMax) {
+        const uint8_t *pages = src.mem && !src_direct ? src.mem : dst.mem && !dst_direct ? dst.mem : nullptr;
+        if (pages) {
+            copy_node = numa::node_of_address(pages + n / 2);
+            have_mask = ::sched_getaffinity(0, sizeof caller_mask, &caller_mask) == 0;
+        }
+    }
+    const int gpu_node = copy_node >= 0 ? device_numa_node(dev) : -1;
+    const int set = copy_node >= 0 && gpu_node >= 0 && copy_node != gpu_node && have_mask ? 1 + copy_node % (kNodeSets - 1) : 0;
+    Staging &s = g_staging[dev * kNodeSets + set];
+    if (set != 0) {
+        std::lock_guard<std::mutex> lock(s.mu);
+        s.node = copy_node;
+        g_node_set_calls.fetch_add(1, std::memory_order_relaxed);
+    }
     struct InFlight { // (reporting: did host-buffer calls ever overlap on a GPU?  modgpu_host_pool_stats)
         InFlight() { if (g_calls_in_flight.fetch_add(1, std::memory_order_relaxed) > 0) g_calls_overlapped.fetch_add(1, std::memory_order_relaxed); }
         ~InFlight() { g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
@@ -620,7 +674,6 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     trace(MODGPU_TRACE_CALL_BEGIN, -1, 0, n);
     struct CallEnd { uint64_t n; ~CallEnd() { trace(MODGPU_TRACE_CALL_END, -1, 0, n); } } call_end{n};
 
-    const bool src_direct = src.mem && src.pinned, dst_direct = dst.mem && dst.pinned;
     const bool all_direct = (!src.mem || src_direct) && (!dst.mem || dst_direct);
     auto account = [&] {
         g_stats.gpu_calls.fetch_add(1, std::memory_order_relaxed);
@@ -717,6 +770,9 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     lease.acquire(pipes * ring, ring);
     pipes = (int)lease.ids.size() / ring;
     job.set_plan(cut_stream(n, chunk, pipes, mem_both ? kRamp : 0));
+    job.copy_node = copy_node;
+    job.have_mask = have_mask;
+    if (have_mask) job.caller_mask = caller_mask;
     for (int k = 0; k < (mem_both ? kLanes : kFileLanes) && k < (int)lease.ids.size(); ++k) job.lanes.push_back(nullptr); // (streams exist after staging_reserve)
     trace(MODGPU_TRACE_SLOTS, -1, (uint64_t)pipes, chunk);
     rc = staging_reserve(s, lease.ids, chunk, !job.slot_kernel && !job.in_dst, !(src_direct && dst_direct) && !job.in_dst);
@@ -830,13 +886,14 @@ int modgpu_host_trace_read(modgpu_host_trace_event_t *out, int cap)
     return (int)g_trace.size();
 }
 
-void modgpu_host_pool_stats(uint64_t out[5])
+void modgpu_host_pool_stats(uint64_t out[6])
 {
     out[0] = g_pool_spawned.load();
     out[1] = g_pool_tasks.load();
     out[2] = g_slot_waits.load();
     out[3] = g_calls_overlapped.load();
     out[4] = (uint64_t)kSlots;
+    out[5] = g_node_set_calls.load();
 }
 
 void modgpu_host_chunking(uint64_t out[4])

@@ -156,6 +156,9 @@ int resolve_device(int device, int *out)
     return MODGPU_OK;
 }
 
+#ifdef MODGPU_TESTING_HOOKS
+std::atomic<int> g_forced_gpu_node{-2}; // modgpu_debug_set_gpu_node: -2 = by sysfs
+#endif
 // NUMA node the GPU behind a logical device hangs off (-1: unknown, or placement switched off by MODGPU_NUMA=0).
 int device_numa_node(int logical)
 {
@@ -163,6 +166,9 @@ int device_numa_node(int logical)
     static int cached[kMaxDevices];
     static bool known[kMaxDevices] = {};
     if (!numa::enabled() || logical < 0 || logical >= kMaxDevices || physical_count() <= 0) return -1;
+#ifdef MODGPU_TESTING_HOOKS
+    if (const int forced = g_forced_gpu_node.load(std::memory_order_relaxed); forced >= -1) return forced; // modgpu_debug_set_gpu_node
+#endif
     std::lock_guard<std::mutex> lock(mu);
     if (!known[logical]) {
         char bdf[64] = {};
@@ -1437,6 +1443,7 @@ void modgpu_debug_set_launch(int variant, uint32_t grid_cap)
 }
 
 void modgpu_debug_set_pcie_grid(uint32_t cap) { g_pcie_grid.store(cap, std::memory_order_relaxed); }
+void modgpu_debug_set_gpu_node(int node) { g_forced_gpu_node.store(node >= -1 ? node : -2, std::memory_order_relaxed); }
 void modgpu_debug_set_pinned_mode(int mode) { g_pinned_mode.store(mode, std::memory_order_relaxed); }
 void modgpu_debug_set_staged_mode(int mode) { g_staged_mode.store(mode, std::memory_order_relaxed); }
 

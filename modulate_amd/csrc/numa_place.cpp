@@ -11,6 +11,7 @@
 #include <cstring>
 #include <algorithm>
 #include <fstream>
+#include <mutex>
 #include <thread>
 
 namespace modgpu {
@@ -130,6 +131,43 @@ int run_on_node(const std::string &sysfs, int node)
     int n = 0;
     for (int c : cpus)
         if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET(c, &now)) { // never widen what the process was given
+            CPU_SET(c, &want);
+            ++n;
+        }
+    return n > 0 && ::sched_setaffinity(0, sizeof want, &want) == 0 ? 0 : -1;
+}
+
+int node_of_address(const void *p)
+{
+    if (!p) return -1;
+    int node = -1;
+    // (no libnuma in the image: the system call itself; 3 = MPOL_F_NODE | MPOL_F_ADDR)
+    if (::syscall(SYS_get_mempolicy, &node, nullptr, 0ul, const_cast<void *>(p), 3ul) != 0) return -1;
+    return node;
+}
+
+int move_to_node(int node, const void *allowed_cpu_set, size_t set_bytes)
+{
+    constexpr int kMaxNodes = 64;
+    static std::mutex mu;
+    static std::vector<int> cached[kMaxNodes];
+    static bool known[kMaxNodes] = {};
+    if (node < 0 || node >= kMaxNodes || !allowed_cpu_set || set_bytes < sizeof(cpu_set_t)) return -1;
+    std::vector<int> cpus;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!known[node]) {
+            cached[node] = cpus_of_node("/sys", node);
+            known[node] = true;
+        }
+        cpus = cached[node];
+    }
+    const cpu_set_t *allowed = static_cast<const cpu_set_t *>(allowed_cpu_set);
+    cpu_set_t want;
+    CPU_ZERO(&want);
+    int n = 0;
+    for (int c : cpus)
+        if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET(c, allowed)) {
             CPU_SET(c, &want);
             ++n;
         }

@@ -39,5 +39,12 @@ void prefault(void *p, size_t bytes, int threads, const std::string &sysfs, int 
 // Restricts the calling thread to the CPUs of `node` (sched_setaffinity).  0 = done, -1 = left as it was.
 int run_on_node(const std::string &sysfs, int node);
 
+// NUMA node the page holding `p` lives on (get_mempolicy; a page not yet present is faulted in by the question).  -1 = unknown.
+int node_of_address(const void *p);
+// Moves the calling (worker) thread to the CPUs of `node` that `allowed` -- the affinity mask of the thread it works for --
+// contains; unlike run_on_node this can take a thread from one node to another.  The node's CPU list is read from /sys once per
+// node.  0 = done, -1 = left as it was.
+int move_to_node(int node, const void *allowed_cpu_set, size_t set_bytes);
+
 } // namespace numa
 } // namespace modgpu

@@ -45,6 +45,7 @@ def hooks(lib):
             M.debug_set_batch(0)
             M.debug_inject_failures(0)
             M.debug_inject_failure_at(0, -1)
+            M.debug_set_gpu_node(-2)
 
 
 def want(pt, key, off=0):
@@ -330,6 +331,44 @@ def test_gpu_lost_in_the_middle_of_a_call(hooks, tmp_path):
     finally:
         sys.argv = argv
         M.debug_inject_failure_at(0, -1)
+
+
+def test_staging_set_of_another_numa_node(hooks):
+    """Round 5: a call whose pageable pages live on another NUMA node than the GPU's takes that node's staging set -- slots from
+    the library's own placed mapping (reserve, mbind, touch, hipHostRegister) instead of hipHostMalloc, workers bound to the node.
+    This machine may have one node; the library is told its GPU hangs off node 1, so that node 0's pages are "elsewhere".  Parity
+    on sizes that grow the slots (free + re-place), a failure injected in the middle of such a call, then back to the GPU's set."""
+    before = M.host_pool_stats()["calls_on_another_nodes_set"]
+    M.debug_set_gpu_node(1)
+    try:
+        for n in ((3 << 20) + 1, (17 << 20) + 5, (5 << 20) - 3):
+            pt = O.splitmix_bytes(n, n)
+            assert np.array_equal(M.cycle_host(pt.copy(), M.KEY_PS4), want(pt, M.KEY_PS4)), n
+        moved = M.host_pool_stats()["calls_on_another_nodes_set"] - before
+        if moved == 0:
+            pytest.skip("the kernel would not say which node a page is on (get_mempolicy refused): nothing to place")
+        assert moved == 3
+        pt = O.splitmix_bytes((12 << 20) + 5, 77)
+        buf = pt.copy()
+        M.debug_inject_failure_at(M.INJECT_PIECE_MIDDLE, M.STAGE_SYNC)
+        M.cycle_auto_host(buf, M.KEY_PS4)
+        assert np.array_equal(buf, want(pt, M.KEY_PS4)) and not M.debug_injection_armed()
+        # two callers at once on that set
+        out = {}
+
+        def run(i):
+            p = O.splitmix_bytes((9 << 20) + i, i)
+            out[i] = np.array_equal(M.cycle_host(p.copy(), M.KEY_PS3, device=0), want(p, M.KEY_PS3))
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert out == {0: True, 1: True, 2: True}
+    finally:
+        M.debug_set_gpu_node(-2)
+    at = M.host_pool_stats()["calls_on_another_nodes_set"]
+    pt = O.splitmix_bytes((4 << 20) + 9, 5)
+    assert np.array_equal(M.cycle_host(pt.copy(), M.KEY_PS4), want(pt, M.KEY_PS4))
+    assert M.host_pool_stats()["calls_on_another_nodes_set"] == at  # the GPU's own set again
 
 
 def test_ticket_ring_under_concurrent_streams(hooks, lib):

@@ -422,6 +422,45 @@ def test_gpu_lost_in_the_middle_of_a_call(gpu, case):
     assert r.returncode == 0 and "MIDCALL_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+_OTHER_NODE_CHILD = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+def cpus(n):
+    out = []
+    for part in open("/sys/devices/system/node/node%%d/cpulist" %% n).read().strip().split(","):
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+nodes = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
+import modulate_amd as M
+from oracle import oracle as O
+gpu_node = M.device_numa_node(0)
+others = [n for n in nodes if n != gpu_node and set(cpus(n)) & os.sched_getaffinity(0)]
+if gpu_node < 0 or not others:
+    print("OTHER_NODE_SKIP"); sys.exit(0)
+os.sched_setaffinity(0, set(cpus(others[0])) & os.sched_getaffinity(0))   # this thread, and the pages it touches from now on
+before = M.host_pool_stats()["calls_on_another_nodes_set"]
+for n in ((3 << 20) + 1, (64 << 20) + 5, (20 << 20) - 3):
+    pt = O.splitmix_bytes(n, n & 0xFFFF)          # allocated and first touched over there
+    want = O.cycle(pt.copy(), O.KEY_PS4)
+    got = M.cycle_host(pt.copy(), M.KEY_PS4)
+    assert np.array_equal(got, want), n
+    assert np.array_equal(M.cycle_host(got, M.KEY_PS4), pt), n
+took = M.host_pool_stats()["calls_on_another_nodes_set"] - before
+assert took == 6, took
+print("OTHER_NODE_OK", gpu_node, others[0])
+"""
+
+
+def test_staged_route_when_the_callers_pages_are_on_the_other_socket(gpu):
+    """Round 5 (profiles/r05_staged_numa.txt): a caller whose pageable pages live on another NUMA node than the GPU's gets that
+    node's staging set -- slots placed there by the library (reserve, mbind, touch, hipHostRegister), workers bound there.  A child
+    moves itself to the other node's CPUs, allocates there, and must get the oracle's bytes and the counter that says which set
+    served it.  Skips itself on a one-node machine."""
+    r = subprocess.run([sys.executable, "-c", _OTHER_NODE_CHILD % ROOT], capture_output=True, text=True, env=dict(os.environ), timeout=600)
+    assert r.returncode == 0 and ("OTHER_NODE_OK" in r.stdout or "OTHER_NODE_SKIP" in r.stdout), r.stdout[-2000:] + r.stderr[-2000:]
+
+
 FUZZ_CASES = [("large", 1), ("large", 2), ("large", 3), ("large", 7), ("large", None), ("small", 1), ("small", 5), ("small", None),
               ("queue", 1), ("queue", 2), ("queue", 3), ("queue", 5), ("queue", 16), ("queue", None)]
 

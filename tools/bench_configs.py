@@ -135,6 +135,9 @@ def main():
                              "min_gpu_bytes": M.min_gpu_bytes(), "host_loop_isa": M.host_loop_isa()}
 
     if not sections & {"c4", "c5"}:
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        with open(a.out, "w") as f:
+            json.dump(res, f, indent=1)
         print(json.dumps(res, indent=1))
         return
     # ---- config 4: 100k synthetic entries -> multi-part .ark + encrypted header, 1 GPU
