@@ -44,7 +44,16 @@ lspcounters)  # profiles/r05_lsp_counters.json: reads in flight and fabric read 
     timeout -k 10 240 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_CYCLE_sum --output-format csv -d $D/pass1 -- tools/ubench_queue_rw 4294967296 200 2 > $D/pass1.log 2>&1
     timeout -k 10 120 tools/ubench_queue_rw 4294967296 200 8 > $D/rates.txt 2>&1
     python3 tools/summarize_memside.py $D > $O/r05_lsp_counters.json ;;
+numa)         # profiles/r05_staged_numa.txt: the staged route with the caller on either socket (cpu lists of this pool's nodes: see lscpu)
+    for i in 1 2 3 4; do for cpus in 64-127,192-255 0-63,128-191; do
+      taskset -c $cpus modulate_amd/bin/modbench --route staged --mib 64 --reps 8 > $O/r05_numa_tmp.log
+      grep "^placement\|^calls\|^staging" $O/r05_numa_tmp.log | cut -c1-130 >> $O/r05_numa.txt
+    done; done ;;
+bench)        # profiles/r05_bench.json, r05_pmc_summary.json (+ profiles/pmc_summary.json, which bench.py replays), r05_rocprofv3_*, r05_configs.json
+    bash tools/profile.sh r05
+    python3 bench.py --steps 20 --warmup 5 > $O/r05_bench.json
+    python3 tools/bench_configs.py --out $O/r05_configs.json ;;
 crossover)    # profiles/r05_small_call_crossover.txt: both engines per call (the table MODGPU_HOST_POLICY=fastest decides by)
     modulate_amd/bin/modbench --hostcall > $O/r05_hostcall.txt ;;
-*) echo "usage: tools/reproduce_r05.sh build | pcie [tag] | grid | wake | lsp | lspcounters | crossover" ;;
+*) echo "usage: tools/reproduce_r05.sh build | pcie [tag] | grid | wake | lsp | lspcounters | numa | bench | crossover" ;;
 esac
