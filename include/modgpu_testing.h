@@ -182,6 +182,10 @@ void modgpu_debug_inject_failure_at(int64_t piece, int stage);
 /* 1 while an armed failure has not fired yet. */
 int modgpu_debug_injection_armed(void);
 
+/* Takes `count` pipeline slots of `device`'s staging set the way a large call does and keeps them until called again with 0 (returns
+ * how many it holds).  With all 32 held, a header-sized call must still be served -- from the two slots only one-slot calls may take. */
+int modgpu_debug_hold_slots(int device, int count);
+
 
 #ifdef __cplusplus
 }

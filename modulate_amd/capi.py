@@ -119,6 +119,7 @@ DEBUG_EXPORTS = {
     "modgpu_debug_inject_failures": (None, [_int]),
     "modgpu_debug_inject_failure_at": (None, [ctypes.c_int64, _int]),
     "modgpu_debug_injection_armed": (_int, []),
+    "modgpu_debug_hold_slots": (_int, [_int, _int]),
 }
 
 
@@ -295,6 +296,11 @@ INJECT_PIECE_LAST, INJECT_PIECE_MIDDLE = -1, -2
 def debug_inject_failure_at(piece, stage):
     """Test hook: the HIP call of `stage` (STAGE_*) for piece `piece` of the next host-buffer / file call fails, once.  stage < 0 disarms."""
     _debug_lib().modgpu_debug_inject_failure_at(piece, stage)
+
+
+def debug_hold_slots(device, count):
+    """Testing flavour: hold `count` pipeline slots of a device's staging set (0 releases); returns how many are held."""
+    return _debug_lib().modgpu_debug_hold_slots(device, count)
 
 
 def debug_injection_armed():

@@ -851,6 +851,20 @@ void modgpu_debug_inject_failure_at(int64_t piece, int stage)
     g_inject_stage.store(stage >= MODGPU_STAGE_FILL && stage <= MODGPU_STAGE_AFTER_DRAIN ? stage : -1, std::memory_order_release);
 }
 int modgpu_debug_injection_armed(void) { return g_inject_stage.load(std::memory_order_acquire) >= 0 ? 1 : 0; }
+// Takes `count` PIPELINE slots of a device's own staging set, as large calls do, and keeps them until called with count = 0: with all
+// of them held, what a header-sized call still finds is exactly the slots reserved for it.  Returns how many are held now.
+int modgpu_debug_hold_slots(int device, int count)
+{
+    static std::mutex mu;
+    static std::unique_ptr<SlotLease> held[kMaxDevices];
+    if (device < 0 || device >= kMaxDevices) return -1;
+    std::lock_guard<std::mutex> lock(mu);
+    held[device].reset();
+    if (count <= 0) return 0;
+    held[device].reset(new SlotLease(g_staging[device * kNodeSets]));
+    held[device]->acquire(count, 2);
+    return (int)held[device]->ids.size();
+}
 // Run-time form of the testing flavour's knobs; not while a host-buffer call is in flight.  Values are clamped like the environment's.
 void modgpu_debug_set_host_tunable(int which, uint64_t value)
 {

@@ -231,6 +231,36 @@ def test_concurrent_callers_share_one_device_and_the_parked_workers(hooks):
     assert all(b["t_ns"] >= a["t_ns"] for a, b in zip(ev, ev[1:]))  # recorded under one lock: monotonic
 
 
+def test_header_sized_calls_do_not_wait_for_large_ones(hooks):
+    """two large staged calls at the default 8 pipelines x 2 slots hold all 32 pipeline slots for their whole length; a
+    header-sized Cycle on that GPU used to wait for one of them to END.  Two of a set's 34 slots are for one-slot calls only: with
+    every pipeline slot held (the hook takes them the way a large call does), header-sized calls -- pageable through one slot, and
+    page-locked memory in place -- are still served at once, two at a time."""
+    assert M.host_pool_stats()["slots_per_device"] == 34
+    assert M.debug_hold_slots(5, 64) == 32  # all a large call could ever get
+    try:
+        done = []
+
+        def small(i):
+            pt = O.splitmix_bytes(4092 + i, i)
+            done.append(np.array_equal(M.cycle_host(pt.copy(), M.KEY_PS4, device=5), want(pt, M.KEY_PS4)))
+            pb = M.PinnedBuffer(300_000, device=5) if False else M.PinnedBuffer(300_000)
+            pb.array[:] = 9
+            M.cycle_host(pb.array, M.KEY_PS3, device=5)
+            done.append(np.array_equal(pb.array, want(np.full(300_000, 9, np.uint8), M.KEY_PS3)))
+            pb.free()
+
+        ts = [threading.Thread(target=small, args=(i,), daemon=True) for i in range(3)]
+        [t.start() for t in ts]
+        [t.join(timeout=60) for t in ts]
+        assert not any(t.is_alive() for t in ts), "a header-sized call is waiting for slots that only large calls should compete for"
+        assert done == [True] * 6
+    finally:
+        assert M.debug_hold_slots(5, 0) == 0
+    big = O.splitmix_bytes((9 << 20) + 1, 4)  # and the pipeline slots are back
+    assert np.array_equal(M.cycle_host(big.copy(), M.KEY_PS4, device=5), want(big, M.KEY_PS4))
+
+
 def test_file_routes_and_their_error_paths(hooks, tmp_path):
     for n in (0, 1, (2 << 20) + 3, (9 << 20) + 11):
         pt = O.splitmix_bytes(n, n + 3)
