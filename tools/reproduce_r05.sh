@@ -44,6 +44,16 @@ lspcounters)  # profiles/r05_lsp_counters.json: reads in flight and fabric read 
     timeout -k 10 240 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_CYCLE_sum --output-format csv -d $D/pass1 -- tools/ubench_queue_rw 4294967296 200 2 > $D/pass1.log 2>&1
     timeout -k 10 120 tools/ubench_queue_rw 4294967296 200 8 > $D/rates.txt 2>&1
     python3 tools/summarize_memside.py $D > $O/r05_lsp_counters.json ;;
+config5)      # profiles/r05_config5_kernels.json: every kernel of configs 4 and 5 end to end (pack, save, load, extract, rebuild, save) under rocprofv3
+    D=$O/r05_c5; rm -rf $D
+    timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 tools/bench_configs.py --sections c4,c5 --out $O/r05_config5_under_rocprofv3.json > $O/r05_config5.log 2>&1
+    find $D -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 tools/summarize_kernel_trace.py {} > $O/r05_config5_kernels.json
+    find $D -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/r05_config5_kernel_stats.csv
+    rm -rf $D ;;
+soak)         # profiles/r05_soak_host.txt, r05_soak.txt, r05_every_state.txt: the final build, randomized and exhaustive
+    timeout -k 10 420 python3 tools/soak_host.py 300 5 > $O/r05_soak_host.txt
+    timeout -k 10 300 python3 tools/soak.py 180 17 > $O/r05_soak.txt
+    timeout -k 10 300 python3 tests/_every_state_child.py > $O/r05_every_state.txt ;;
 numa)         # profiles/r05_staged_numa.txt: the staged route with the caller on either socket (cpu lists of this pool's nodes: see lscpu)
     for i in 1 2 3 4; do for cpus in 64-127,192-255 0-63,128-191; do
       taskset -c $cpus modulate_amd/bin/modbench --route staged --mib 64 --reps 8 > $O/r05_numa_tmp.log
@@ -55,5 +65,5 @@ bench)        # profiles/r05_bench.json, r05_pmc_summary.json (+ profiles/pmc_su
     python3 tools/bench_configs.py --out $O/r05_configs.json ;;
 crossover)    # profiles/r05_small_call_crossover.txt: both engines per call (the table MODGPU_HOST_POLICY=fastest decides by)
     modulate_amd/bin/modbench --hostcall > $O/r05_hostcall.txt ;;
-*) echo "usage: tools/reproduce_r05.sh build | pcie [tag] | grid | wake | lsp | lspcounters | numa | bench | crossover" ;;
+*) echo "usage: tools/reproduce_r05.sh build | pcie [tag] | grid | wake | lsp | lspcounters | config5 | soak | numa | bench | crossover" ;;
 esac
