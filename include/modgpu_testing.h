@@ -142,7 +142,8 @@ void modgpu_debug_set_launch(int variant, uint32_t grid_cap);
  * the environment at load under their old names (MODGPU_HOST_ZEROCOPY_KB, _RING, _SPLIT, _CHUNK_MIN_MB, _RAMP_KB, _LANES, _NTCOPY)
  * and changes them here at run time -- not while a host-buffer call is in flight.  modgpu_host_tunables / _chunking report them. */
 enum { MODGPU_TUNABLE_ZEROCOPY_BYTES = 0, MODGPU_TUNABLE_RING = 1, MODGPU_TUNABLE_SPLIT = 2, MODGPU_TUNABLE_CHUNK_MIN_BYTES = 3,
-       MODGPU_TUNABLE_RAMP_BYTES = 4, MODGPU_TUNABLE_LANES = 5, MODGPU_TUNABLE_NTCOPY = 6 };
+       MODGPU_TUNABLE_RAMP_BYTES = 4, MODGPU_TUNABLE_LANES = 5, MODGPU_TUNABLE_NTCOPY = 6,
+       MODGPU_TUNABLE_FILE_SCHED = 7 /* 1 (the shipped rule): file -> memory is cut and queued like a memory-to-memory call; 0: like the other file routes */ };
 void modgpu_debug_set_host_tunable(int which, uint64_t value);
 
 /* The NUMA node the library believes its GPUs hang off (-1 = unknown, -2 = ask sysfs, the default).  Lets a one-node machine

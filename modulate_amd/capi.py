@@ -266,7 +266,7 @@ def debug_set_staged_mode(mode=0):
     _debug_lib().modgpu_debug_set_staged_mode(mode)
 
 
-HOST_TUNABLES = {"zerocopy_bytes": 0, "ring": 1, "split": 2, "chunk_min_bytes": 3, "ramp_bytes": 4, "lanes": 5, "ntcopy": 6}
+HOST_TUNABLES = {"zerocopy_bytes": 0, "ring": 1, "split": 2, "chunk_min_bytes": 3, "ramp_bytes": 4, "lanes": 5, "ntcopy": 6, "file_sched": 7}
 
 
 def debug_set_host_tunable(name, value):

@@ -140,6 +140,12 @@ MODGPU_KNOB_STORAGE uint64_t kRamp = std::min<uint64_t>((uint64_t)MODGPU_KNOB("M
 MODGPU_KNOB_STORAGE int kLanes = MODGPU_KNOB("MODGPU_HOST_LANES", 4, 0, 8);
 MODGPU_KNOB_STORAGE bool kNtCopy = MODGPU_KNOB("MODGPU_HOST_NTCOPY", 1, 0, 1) != 0;
 constexpr int kFileLanes = 0; // calls with a file on either side keep a stream per slot: lanes made no difference there (profiles/r04_file_routes.txt)
+// file_sched: which schedule FILE -> MEMORY takes (LoadArkData's part cipher): 1 (shipped) = the memory routes' (split / chunk_min / ramp /
+// lanes above), 0 = the file routes' own (~16 chunks of >= 4 MiB, no ramp, a stream per slot), which memory -> file and file -> file
+// always keep: their slow stage is pwrite, which wants few large calls.  Round 4 measured the memory schedule 3-5 % BEHIND on every
+// file route; with round 5's short-launch grid it is ahead where the destination is memory: 33.8 / 39.7 / 44.1 -> 34.7 / 42.0 / 46.8 GB/s
+// at 64 / 392 / 4096 MiB into page-locked memory, and level (within the file system's noise) the other way (profiles/r05_file_routes.txt).
+MODGPU_KNOB_STORAGE int kFileSched = MODGPU_KNOB("MODGPU_HOST_FILE_SCHED", 1, 0, 1);
 
 // ---- host-side timeline of the staged / pinned routes (modgpu_host_trace, reporting only) --------------------------------
 std::atomic<bool> g_trace_on{false};
@@ -740,7 +746,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     // side keeps round 3's (~16 chunks of >= 4 MiB, all alike, a stream per slot): there the slow stage is pread / pwrite, which
     // wants few large calls, and an interleaved A/B of both schedules on the file routes had the new one 3-5 % behind
     // (profiles/r04_file_routes.txt).
-    const bool mem_both = src.mem && dst.mem;
+    const bool mem_both = (src.mem && dst.mem) || (kFileSched != 0 && !src.mem && dst.mem); // (named for what it was: "takes the memory schedule")
     const uint64_t split = mem_both ? kSplit : 16, chunk_min = mem_both ? kChunkMin : std::min<uint64_t>(4ull << 20, kChunk);
     uint64_t chunk = n <= chunk_min ? std::max<uint64_t>(n, 1ull << 20)
                                     : std::min<uint64_t>(kChunk, std::max<uint64_t>(chunk_min, ((n / split) + 0xFFFFF) & ~0xFFFFFull));
@@ -877,6 +883,7 @@ void modgpu_debug_set_host_tunable(int which, uint64_t value)
     case MODGPU_TUNABLE_RAMP_BYTES: kRamp = std::min<uint64_t>(value, kChunk); break;
     case MODGPU_TUNABLE_LANES: kLanes = (int)clamp(value, 0, 8); break;
     case MODGPU_TUNABLE_NTCOPY: kNtCopy = value != 0; break;
+    case MODGPU_TUNABLE_FILE_SCHED: kFileSched = value != 0; break;
     default: break;
     }
 }
