@@ -178,7 +178,7 @@ struct Staging {
     bool busy[kSlots] = {};                     // under mu
     std::deque<std::shared_ptr<Call>> requests; // under mu: one entry per pipeline a call would like a worker for
     int workers = 0, parked = 0;                // under mu
-    int node = -1; // NUMA node this set's slots and workers live on; -1: next to the GPU (where the runtime puts page-locked memory)
+    std::atomic<int> node{-1}; // NUMA node this set's slots and workers live on; -1: next to the GPU (where the runtime puts page-locked memory)
     bool placed[kSlots] = {}; // the slot's pinned buffer is our own placed mapping (numa::reserve + hipHostRegister), not hipHostMalloc's
 };
 // A device has one staging context per NUMA node a caller's pages can be on (round 5, profiles/r05_staged_numa.txt).  The staged
@@ -257,9 +257,9 @@ int staging_reserve(Staging &s, const std::vector<int> &ids, uint64_t need, bool
             s.pinned[i] = nullptr;
             s.pinned_cap[i] = 0;
             s.placed[i] = false;
-            if (s.node >= 0) { // this set's slots live on a named node: our own mapping, bound, touched, then page-locked in place
+            if (const int node = s.node.load(std::memory_order_relaxed); node >= 0) { // this set's slots live on a named node: our own mapping, bound, touched, then page-locked in place
                 void *p = numa::reserve(need);
-                if (p && numa::prefer_node(p, need, s.node) == 0) {
+                if (p && numa::prefer_node(p, need, node) == 0) {
                     numa::prefault(p, need, 1, "/sys", -1);
                     if (hipHostRegister(p, need, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess) {
                         s.pinned[i] = static_cast<uint8_t *>(p);
@@ -552,8 +552,9 @@ struct Call {
 void worker_main(Staging *s, int logical, int phys, cpu_set_t allowed, bool have_allowed)
 {
     // a staging worker's copies run where its set's slots are: next to the GPU, or on the node the set was made for
-    if (s->node >= 0 && have_allowed) (void)numa::move_to_node(s->node, &allowed, sizeof allowed);
-    else if (s->node < 0) run_near_device(logical);
+    const int node = s->node.load(std::memory_order_relaxed);
+    if (node >= 0 && have_allowed) (void)numa::move_to_node(node, &allowed, sizeof allowed);
+    else if (node < 0) run_near_device(logical);
     (void)hipSetDevice(phys); // HIP's current device is per thread
     std::unique_lock<std::mutex> lock(s->mu);
     for (;;) {
@@ -668,9 +669,8 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     const int gpu_node = copy_node >= 0 ? device_numa_node(dev) : -1;
     const int set = copy_node >= 0 && gpu_node >= 0 && copy_node != gpu_node && have_mask ? 1 + copy_node % (kNodeSets - 1) : 0;
     Staging &s = g_staging[dev * kNodeSets + set];
-    if (set != 0) {
-        std::lock_guard<std::mutex> lock(s.mu);
-        s.node = copy_node;
+    if (set != 0) { // (every caller of this set writes the same value: the set's index is a function of the node)
+        if (s.node.load(std::memory_order_relaxed) != copy_node) s.node.store(copy_node, std::memory_order_relaxed);
         g_node_set_calls.fetch_add(1, std::memory_order_relaxed);
     }
     struct InFlight { // (reporting: did host-buffer calls ever overlap on a GPU?  modgpu_host_pool_stats)
