@@ -348,8 +348,10 @@ static int wake_main(Ctx &c, uint64_t n, int trials, int idle_ms)
     const int only = getenv("WAKE_ONLY") ? atoi(getenv("WAKE_ONLY")) : -1;
     if (only >= 0) { // the part as bench.py has it: from modgpu_alloc, which also prepares the device (code object, ring, both kernels resolved)
         void *p = nullptr;
-        MOD(modgpu_alloc(&p, n, 0));
+        const uint64_t want = getenv("WAKE_UPLOAD_BYTES") ? std::max<uint64_t>(n, strtoull(getenv("WAKE_UPLOAD_BYTES"), nullptr, 0)) : n;
+        MOD(modgpu_alloc(&p, want, 0));
         c.buf = (uint8_t *)p;
+        c.cap = want;
         if (getenv("WAKE_WARM")) { // a REAL work-queue launch (two 64 KiB parts share one: ring line, sign-off word and all) before anything is timed
             void *parts[2] = {c.buf, c.buf + (1 << 20)};
             uint64_t sizes[2] = {65536, 65536};
@@ -369,10 +371,15 @@ static int wake_main(Ctx &c, uint64_t n, int trials, int idle_ms)
             hipStream_t const keep_st = c.st;
             if (v == 9) c.st = nullptr;
             if (v == 1) nop(side);
-            for (uint64_t off = 0; off < n; off += kTile) {
+            // WAKE_PAGEABLE=1: the upload's source is ordinary memory (bench.py's numpy tile); WAKE_UPLOAD_BYTES=B: the upload covers B
+            // bytes of the buffer although only the first n are cycled (bench.py uploads its whole 4 GiB part, then cycles 411 MB of it)
+            static uint8_t *const pageable = getenv("WAKE_PAGEABLE") ? (uint8_t *)memset(malloc(kTile), 0x37, kTile) : nullptr;
+            const uint64_t up = getenv("WAKE_UPLOAD_BYTES") ? std::min<uint64_t>(strtoull(getenv("WAKE_UPLOAD_BYTES"), nullptr, 0), c.cap) : n;
+            const uint8_t *from = pageable ? pageable : c.pinned;
+            for (uint64_t off = 0; off < up; off += kTile) {
                 if (v == 2) nop(side);
-                if (v >= 5) MOD(modgpu_h2d(c.buf + off, c.pinned, std::min(kTile, n - off), 0));
-                else CHECK(hipMemcpy(c.buf + off, c.pinned, std::min(kTile, n - off), hipMemcpyHostToDevice));
+                if (v >= 5) MOD(modgpu_h2d(c.buf + off, from, std::min(kTile, up - off), 0));
+                else CHECK(hipMemcpy(c.buf + off, from, std::min(kTile, up - off), hipMemcpyHostToDevice));
             }
             if (v == 7) hipLaunchKernelGGL(touch_kernel, dim3(64), dim3(256), 0, side, (const uint32_t *)c.buf, n / 65536, c.sink);
             float w = 0;
