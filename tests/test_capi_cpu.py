@@ -440,8 +440,8 @@ def test_lab_kernel_at_the_products_settings_is_the_products_loop():
                 h[ln.split()[0]] += 1
         return h
     product = histogram(r"_Z25modgpu_cycle_queue_kernelILi4ELi1024EEv14CycleQueueArgs")
-    # <U 4, BLOCK 1024, ALG 2, SAUX sc1|nt, TRACE 0, DEPTH 1, MODE_FULL, LAUX nt, B1 1, B2 1, TSPLIT 0, TK 1, TLOOP 0, LSP 0>
-    lab = histogram(r"_Z22lab_cycle_queue_kernelILi4ELi1024ELi2ELi18ELi0ELi1ELi0ELi2ELi1ELi1ELi0ELi1ELi0ELi0EEv12LabQueueArgs")
+    # <U 4, BLOCK 1024, ALG 2, SAUX sc1|nt, TRACE 0, DEPTH 1, MODE_FULL, LAUX nt, B1 1, B2 1, TSPLIT 0, TK 1, TLOOP 0, LSP 0, HSB 0>
+    lab = histogram(r"_Z22lab_cycle_queue_kernelILi4ELi1024ELi2ELi18ELi0ELi1ELi0ELi2ELi1ELi1ELi0ELi1ELi0ELi0ELi0EEv12LabQueueArgs")
     bookkeeping = {"s_waitcnt", "s_nop", "s_mov_b32", "s_mov_b64"}
     diff = {k: (product[k], lab[k]) for k in set(product) | set(lab) if product[k] != lab[k]}
     assert all(k in bookkeeping and abs(a - b) <= 4 for k, (a, b) in diff.items()), diff

@@ -37,12 +37,15 @@ struct LabArgs : CycleArgs {
     uint32_t *queue = nullptr, *queue_done = nullptr; // {ticket counter, workgroups done}
     uint32_t queue_seq = 0, main_groups = 0, helper_below_mhz = 0;
     uint32_t tail_chunks = 0; // TSPLIT != 0: this many chunks at the end of the index space are handed out as 2^TSPLIT pieces each
+    uint32_t standby_ticks = 0; // see LabQueueArgs
     uint64_t *trace = nullptr; // TRACE = 1: per-workgroup timestamps (wall_clock64, 100 MHz), kTraceSlots words each: [0] start, [1+k] end of trip k, [last] XCC id
 };
 struct LabQueueArgs {
     CycleQueueArgs q;
     uint64_t *trace;
     uint32_t tail_chunks;
+    uint32_t standby_ticks; // round 5, helpers: 0 = look at the clock once and join or leave (the product); else keep looking, every ~50 us, for this
+                            // many ticks of the 100 MHz counter, sleeping in between WITHOUT touching memory, and join the moment the clock is low
 };
 // the product's table of one part for a buffer planned as CycleArgs (chunk = the instantiation's bytes per workgroup trip)
 inline CycleQueueArgs lab_queue_table_of(const LabArgs &a, uint32_t chunk)
@@ -68,7 +71,7 @@ inline CycleQueueArgs lab_queue_table_of(const LabArgs &a, uint32_t chunk)
     for (int k = 1; k <= kCycleBatchMax; ++k) q.start[k] = total;
     return q;
 }
-inline LabQueueArgs lab_queue_args_of(const LabArgs &a, uint32_t chunk) { return {lab_queue_table_of(a, chunk), a.trace, a.tail_chunks}; }
+inline LabQueueArgs lab_queue_args_of(const LabArgs &a, uint32_t chunk) { return {lab_queue_table_of(a, chunk), a.trace, a.tail_chunks, a.standby_ticks}; }
 
 // ---- the static-map kernel with every knob ------------------------------------------------------------------
 // PIPE  = 0: load, compute, store per trip.  1: software pipeline, the next trip's loads are issued
@@ -266,8 +269,10 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
 //         2 = the first U/2 words of chunk k+2 are issued at the END of trip k, behind its store burst and the ticket read (the
 //             buffer they land in has just been stored), the other U/2 behind trip k+1's first barrier as before.
 //         DEPTH 1, TK 1, no TSPLIT.
+// HSB   (round 5) = 1: helper workgroups STAND BY instead of deciding once: lane 0 sleeps (s_sleep and the real-time counter only, no memory
+//         traffic), looks at the shader clock again every ~50 us for la.standby_ticks ticks of the 100 MHz counter, and joins the moment it is low.
 template <int U, int BLOCK, int ALG, int SAUX = AUX_SC1, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int LAUX = AUX_NT, int B1 = 1, int B2 = 1,
-          int TSPLIT = 0, int TK = 1, int TLOOP = 0, int LSP = 0>
+          int TSPLIT = 0, int TK = 1, int TLOOP = 0, int LSP = 0, int HSB = 0>
 __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void lab_cycle_queue_kernel(LabQueueArgs la)
 {
     static_assert(LSP == 0 || (DEPTH == 1 && TK == 1 && TSPLIT == 0 && TLOOP == 0 && U % 2 == 0), "LSP is an experiment on the product's loop shape");
@@ -486,14 +491,37 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
         // profiles/r03_tune_dvfs.txt keeps that row.)
         uint32_t t = 0xFFFFFFFFu;
         if (tid == 0) {
-            const uint64_t t0 = wall_clock64(), c0 = clock64();
-            uint64_t t1;
-            do {
-                __builtin_amdgcn_s_sleep(4);
-                t1 = wall_clock64();
-            } while (t1 - t0 < 200);
-            const uint64_t mhz = ((clock64() - c0) * 100) / (t1 - t0);
-            if (mhz < a.helper_below_mhz) t = __hip_atomic_fetch_add(a.queue, (uint32_t)PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (HSB == 0) { // the product's: look once
+                const uint64_t t0 = wall_clock64(), c0 = clock64();
+                uint64_t t1;
+                do {
+                    __builtin_amdgcn_s_sleep(4);
+                    t1 = wall_clock64();
+                } while (t1 - t0 < 200);
+                const uint64_t mhz = ((clock64() - c0) * 100) / (t1 - t0);
+                if (mhz < a.helper_below_mhz) t = __hip_atomic_fetch_add(a.queue, (uint32_t)PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const uint64_t born = wall_clock64();
+                for (;;) {
+                    const uint64_t t0 = wall_clock64(), c0 = clock64();
+                    uint64_t t1;
+                    do {
+                        __builtin_amdgcn_s_sleep(4);
+                        t1 = wall_clock64();
+                    } while (t1 - t0 < 200);
+                    const uint64_t mhz = ((clock64() - c0) * 100) / (t1 - t0);
+                    if (mhz < a.helper_below_mhz) {
+                        t = __hip_atomic_fetch_add(a.queue, (uint32_t)PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    if (t1 - born >= la.standby_ticks) break;
+                    uint64_t t2;
+                    do { // ~50 us asleep: s_sleep and the real-time counter only, no memory traffic
+                        __builtin_amdgcn_s_sleep(127);
+                        t2 = wall_clock64();
+                    } while (t2 - t1 < 5000);
+                }
+            }
             q_next[0] = t;
         }
         __syncthreads();

@@ -16,7 +16,7 @@ def label(kernel):
         return {"0": "read_only", "1": "write_only", "2": "copy"}[m.group(1)]
     if "modgpu_cycle_queue_kernel" in kernel:
         return "product"
-    m = re.search(r"lab_cycle_queue_kernel<.*, (\d)>\(", kernel)  # the last template argument is LSP (tools/cycle_kernel_lab.h)
+    m = re.search(r"lab_cycle_queue_kernel<.*, (\d), \d>\(", kernel)  # the last template arguments are LSP, HSB (tools/cycle_kernel_lab.h)
     if m:
         return "lab_lsp_%s" % m.group(1)
     return None

@@ -12,6 +12,7 @@
 #include <unistd.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -50,11 +51,11 @@ template <int U, int BLOCK, int ALG, int PIPE, int MODE, int SAUX = 16, int SYNC
 }
 
 // ALG: 2 = the shipped keystream sequence (canonicalising carry out of the fold, 3 instructions per byte), 1 = round 2's (4 per byte)
-template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int SAUX = 16, int LAUX = 2, int B1 = 1, int B2 = 1, int ALG = 2, int TSPLIT = 0, int TK = 1, int TLOOP = 0, int LSP = 0>
+template <int U, int BLOCK, int TRACE = 0, int DEPTH = 1, int MODE = MODE_FULL, int SAUX = 16, int LAUX = 2, int B1 = 1, int B2 = 1, int ALG = 2, int TSPLIT = 0, int TK = 1, int TLOOP = 0, int LSP = 0, int HSB = 0>
 void launch_queue(const LabArgs &a, uint32_t grid, hipStream_t st)
 {
     // (the kernel takes a table of parts: one buffer planned as a CycleArgs is a table of one)
-    hipLaunchKernelGGL((lab_cycle_queue_kernel<U, BLOCK, ALG, SAUX, TRACE, DEPTH, MODE, LAUX, B1, B2, TSPLIT, TK, TLOOP, LSP>), dim3(grid), dim3(BLOCK), 0, st,
+    hipLaunchKernelGGL((lab_cycle_queue_kernel<U, BLOCK, ALG, SAUX, TRACE, DEPTH, MODE, LAUX, B1, B2, TSPLIT, TK, TLOOP, LSP, HSB>), dim3(grid), dim3(BLOCK), 0, st,
                        lab_queue_args_of(a, (uint32_t)U * BLOCK * 16));
 }
 // the kernels the product ships, instantiated from the product header itself
@@ -314,8 +315,21 @@ static int dvfs_main(uint64_t n, int launches)
     CHECK(hipMemset(a.queue, 0, 64));
     a.head_ptr = buf; a.body = buf; a.body_words = n / 16; a.tail_ptr = buf + n;
     a.base_head = a.base_body = a.base_tail = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
-    struct Shape { const char *name; void (*launch)(const LabArgs &, uint32_t, hipStream_t); uint32_t grid; uint32_t main = 0; uint32_t below = 0; };
+    struct Shape { const char *name; void (*launch)(const LabArgs &, uint32_t, hipStream_t); uint32_t grid; uint32_t main = 0; uint32_t below = 0; uint32_t standby_pct = 0; };
     const Shape shapes[] = {
+        // round 5: helpers that STAND BY -- asleep, no memory traffic -- and look at the clock again every ~50 us for standby_pct % of the launch's
+        // expected duration (n / 3.5 TB/s), instead of looking once; "never join" rows price the standing by itself
+        {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers below 1850 MHz, decide once (shipped)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1850},
+        {"... standing by for 80 % of the launch", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1850, 80},
+        {"... standing by for 50 % of the launch", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1850, 50},
+        {"... standing by for 40 % of the launch", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1850, 40},
+        {"... standing by for 30 % of the launch", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1850, 30},
+        {"... standing by for 40 % of the launch, never joining (what standing by costs)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1, 40},
+        {"... standing by for 20 % of the launch, never joining (what standing by costs)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1, 20},
+        {"... standing by for 80 % of the launch, never joining (what standing by costs)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1, 80},
+        {"... decide once, never joining", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1},
+        {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers below 1850 MHz, decide once (shipped), again", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1850},
+        {"... standing by for 80 % of the launch, again", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1850, 80},
         {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers joining below 1850 MHz (shipped)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1850},
         {"the same with round 3's ticket timing (TK 0)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 0>, 256, 200, 1850},
         {"PRODUCT kernel, 200 main + 56 helpers below 1850 MHz", launch_product_queue, 256, 200, 1850},
@@ -338,6 +352,8 @@ static int dvfs_main(uint64_t n, int launches)
         a.stride_mul2 = 2u * lcg::powmod(lcg::A, ((uint64_t)sh.grid * 65536) % lcg::PERIOD);
         a.main_groups = sh.main;
         a.helper_below_mhz = sh.below;
+        a.standby_ticks = (uint32_t)((double)n / 3.5e12 * 1e8 * sh.standby_pct / 100.0);
+        if (getenv("DVFS_ONLY_STANDBY") && !(sh.standby_pct || strstr(sh.name, "decide once"))) continue;
         CHECK(hipDeviceSynchronize());
         usleep(300000);
         CHECK(hipMemsetAsync(d_probe, 0, samples * 16, pst));

@@ -137,8 +137,8 @@ int main(int argc, char **argv)
                 else if (m == WRITE) hipLaunchKernelGGL(rw_kernel<WRITE>, dim3(grid), dim3(BLOCK), 0, st, buf, n, queue, sink);
                 else if (m == COPY) hipLaunchKernelGGL(rw_kernel<COPY>, dim3(grid), dim3(BLOCK), 0, st, buf, n, queue, sink);
                 else if (m == FULL) hipLaunchKernelGGL((modgpu_cycle_queue_kernel<U, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, qa);
-                else if (m == 4) hipLaunchKernelGGL((lab_cycle_queue_kernel<U, BLOCK, 2, 18, 0, 1, MODE_FULL, 2, 1, 1, 0, 1, 0, 1>), dim3(grid), dim3(BLOCK), 0, st, lqa);
-                else hipLaunchKernelGGL((lab_cycle_queue_kernel<U, BLOCK, 2, 18, 0, 1, MODE_FULL, 2, 1, 1, 0, 1, 0, 2>), dim3(grid), dim3(BLOCK), 0, st, lqa);
+                else if (m == 4) hipLaunchKernelGGL((lab_cycle_queue_kernel<U, BLOCK, 2, 18, 0, 1, MODE_FULL, 2, 1, 1, 0, 1, 0, 1, 0>), dim3(grid), dim3(BLOCK), 0, st, lqa);
+                else hipLaunchKernelGGL((lab_cycle_queue_kernel<U, BLOCK, 2, 18, 0, 1, MODE_FULL, 2, 1, 1, 0, 1, 0, 2, 0>), dim3(grid), dim3(BLOCK), 0, st, lqa);
             }
             CHECK(hipEventRecord(e1, st));
             CHECK(hipEventSynchronize(e1));
