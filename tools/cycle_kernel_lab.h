@@ -500,6 +500,10 @@ __global__ __launch_bounds__(BLOCK) MODGPU_KEEP_OFF_THE_FIXED_TEMPORARIES void l
                 } while (t1 - t0 < 200);
                 const uint64_t mhz = ((clock64() - c0) * 100) / (t1 - t0);
                 if (mhz < a.helper_below_mhz) t = __hip_atomic_fetch_add(a.queue, (uint32_t)PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if constexpr (HSB == 2) { // diagnostic: sleep la.standby_ticks, then join whatever the clock (what does a LATE joiner do to a launch?)
+                const uint64_t born = wall_clock64();
+                while (wall_clock64() - born < la.standby_ticks) __builtin_amdgcn_s_sleep(127);
+                t = __hip_atomic_fetch_add(a.queue, (uint32_t)PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 const uint64_t born = wall_clock64();
                 for (;;) {

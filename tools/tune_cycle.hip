@@ -179,8 +179,14 @@ static int trace_main(uint64_t n, uint32_t grid_cap, bool queue, int variant, ui
         {"TK + TSPLIT 1", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 1, 1>, launch_queue<4, 1024, 1, 1, MODE_FULL, 18, 2, 1, 1, 2, 1, 1>},
         {"TLOOP + TSPLIT 1: halves in a second, cold loop", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 1, 0, 1>, launch_queue<4, 1024, 1, 1, MODE_FULL, 18, 2, 1, 1, 2, 1, 0, 1>},
         {"TLOOP + TSPLIT 2: quarters in a second, cold loop", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 2, 0, 1>, launch_queue<4, 1024, 1, 1, MODE_FULL, 18, 2, 1, 1, 2, 2, 0, 1>},
+        {"HSB 2 diagnostic: 56 helpers join after sleeping 30 % of the launch (grid 256 = 200 main + 56)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 2>, launch_queue<4, 1024, 1, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 2>},
     };
-    if (variant < 0 || variant > 6) variant = 0;
+    if (variant < 0 || variant > 7) variant = 0;
+    if (variant == 7) {
+        a.main_groups = 200;
+        a.helper_below_mhz = 1850;
+        a.standby_ticks = (uint32_t)((double)n / 3.5e12 * 1e8 * 0.30);
+    }
     printf("== %s schedule%s%s, tail_chunks=%u, %s\n", queue ? "work-queue" : "static", queue ? ": " : "", queue ? kQueueVariants[variant].name : "", tail_chunks,
            cold ? "COLD (768 MB memset in front of each traced launch)" : "warm, back to back behind an untraced launch");
     const uint32_t base0 = lcg::state_residue(lcg::key_residue((int32_t)0x90cfc0ab), 0);
@@ -318,18 +324,26 @@ static int dvfs_main(uint64_t n, int launches)
     struct Shape { const char *name; void (*launch)(const LabArgs &, uint32_t, hipStream_t); uint32_t grid; uint32_t main = 0; uint32_t below = 0; uint32_t standby_pct = 0; };
     const Shape shapes[] = {
         // round 5: helpers that STAND BY -- asleep, no memory traffic -- and look at the clock again every ~50 us for standby_pct % of the launch's
-        // expected duration (n / 3.5 TB/s), instead of looking once; "never join" rows price the standing by itself
-        {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers below 1850 MHz, decide once (shipped)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1850},
-        {"... standing by for 80 % of the launch", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1850, 80},
-        {"... standing by for 50 % of the launch", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1850, 50},
-        {"... standing by for 40 % of the launch", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1850, 40},
-        {"... standing by for 30 % of the launch", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1850, 30},
-        {"... standing by for 40 % of the launch, never joining (what standing by costs)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1, 40},
-        {"... standing by for 20 % of the launch, never joining (what standing by costs)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1, 20},
-        {"... standing by for 80 % of the launch, never joining (what standing by costs)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1, 80},
-        {"... decide once, never joining", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1},
-        {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers below 1850 MHz, decide once (shipped), again", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1850},
-        {"... standing by for 80 % of the launch, again", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 256, 200, 1850, 80},
+        // expected duration (n / 3.5 TB/s), instead of looking once; "never join" rows price the standing by itself.  Grid 248 (31 workgroups per XCD), not 256:
+        // the clock probe's wave occupies a CU of one XCD for the whole series, so that XCD's 32nd persistent 1024-thread workgroup would not start
+        // before another one there has left -- harmless when helpers decide at once, but a helper that stands by would BEGIN its stand-by when the
+        // launch is already over and stretch it by that long (what the first runs of this experiment measured: profiles/r05_standby.txt)
+        {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers below 1850 MHz, decide once (shipped)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 248, 200, 1850},
+        {"... standing by for 80 % of the launch", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 248, 200, 1850, 80},
+        {"... standing by for 50 % of the launch", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 248, 200, 1850, 50},
+        {"... standing by for 40 % of the launch", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 248, 200, 1850, 40},
+        {"... standing by for 30 % of the launch", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 248, 200, 1850, 30},
+        {"... standing by for 40 % of the launch, never joining (what standing by costs)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 248, 200, 1, 40},
+        {"... standing by for 20 % of the launch, never joining (what standing by costs)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 248, 200, 1, 20},
+        {"... standing by for 80 % of the launch, never joining (what standing by costs)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 248, 200, 1, 80},
+        {"... decide once, never joining", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 248, 200, 1},
+        // diagnostic (HSB 2): every helper joins, whatever the clock, after sleeping for pct % of the launch -- what a LATE joiner does to a launch
+        {"... diag: all 56 helpers join at once (0 %)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 2>, 248, 200, 1850, 0},
+        {"... diag: all 56 helpers join after 10 % of the launch", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 2>, 248, 200, 1850, 10},
+        {"... diag: all 56 helpers join after 30 % of the launch", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 2>, 248, 200, 1850, 30},
+        {"... diag: all 56 helpers join after 60 % of the launch", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 2>, 248, 200, 1850, 60},
+        {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers below 1850 MHz, decide once (shipped), again", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 248, 200, 1850},
+        {"... standing by for 80 % of the launch, again", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 1, 0, 0, 1>, 248, 200, 1850, 80},
         {"queue 64 KiB, FULL alg 2, 200 main + 56 helpers joining below 1850 MHz (shipped)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18>, 256, 200, 1850},
         {"the same with round 3's ticket timing (TK 0)", launch_queue<4, 1024, 0, 1, MODE_FULL, 18, 2, 1, 1, 2, 0, 0>, 256, 200, 1850},
         {"PRODUCT kernel, 200 main + 56 helpers below 1850 MHz", launch_product_queue, 256, 200, 1850},
@@ -353,7 +367,8 @@ static int dvfs_main(uint64_t n, int launches)
         a.main_groups = sh.main;
         a.helper_below_mhz = sh.below;
         a.standby_ticks = (uint32_t)((double)n / 3.5e12 * 1e8 * sh.standby_pct / 100.0);
-        if (getenv("DVFS_ONLY_STANDBY") && !(sh.standby_pct || strstr(sh.name, "decide once"))) continue;
+        if (getenv("DVFS_ONLY_STANDBY") && !(sh.standby_pct || strstr(sh.name, "decide once") || strstr(sh.name, "diag"))) continue;
+        if (getenv("DVFS_ONLY_DIAG") && !(strstr(sh.name, "diag") || strstr(sh.name, "(shipped)"))) continue;
         CHECK(hipDeviceSynchronize());
         usleep(300000);
         CHECK(hipMemsetAsync(d_probe, 0, samples * 16, pst));
