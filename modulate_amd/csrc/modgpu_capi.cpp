@@ -446,6 +446,11 @@ constexpr uint32_t kPcieGridShort = 32u;
 constexpr uint64_t kPcieShortMax = 64ull << 20;
 
 // Workgroups of a work-queue launch over `chunks` chunks on a device of `cus` CUs: most main workgroups, and helpers.
+// (A persistent 1024-thread, 128-VGPR workgroup needs a CU to itself, and the grid asks for every CU: whenever another kernel
+//  holds part of a CU -- a caller's own work on another stream, a profiler's probe -- the LAST workgroup of its XCD, a helper
+//  since helpers are dispatched last, does not start before another one there has left.  A helper looks at the clock for 2 us
+//  and leaves, or finds the tickets gone: harmless by construction.  It is the reason helpers must never wait for anything --
+//  round 5's stand-by experiment tripped over exactly this, profiles/r05_standby.txt.)
 void queue_grid(uint64_t chunks, uint64_t cus, uint64_t *main_cap, uint64_t *helpers)
 {
     const uint32_t grid_cap = forced_grid_cap();
