@@ -2,33 +2,36 @@
 // memory or in a file get through the kernel and back (include/modgpu.h: modgpu_cycle_host,
 // modgpu_cycle_file*, and through them CEncryptionCycler::Cycle and the CArk part cipher).
 //
-// Three routes, picked per call:
+// Three routes, picked per call (rates: profiles/r05_pcie_route_*.json, one MI355X behind PCIe 5 x16):
 //
 //   pinned            the caller's pages are page-locked (modgpu_host_alloc): ONE kernel launch reads and
 //                     writes them across PCIe where they lie -- no host copy, no DMA submissions, no
-//                     device slots, no host threads.  50 GB/s of payload at 64 MiB .. 4 GiB, each byte
-//                     crossing the link twice (profiles/r02_sweep_pinned_routes.txt).  (Alternative, same
-//                     bytes, slower at 26-29 GB/s and kept selectable: chunked H2D -> kernel in HBM -> D2H
-//                     straight from / to the pages through a ring of device slots.)  When only one side of a
-//                     file stream is pinned memory, that side is DMA'd directly and the file side staged.
-//   pageable, large   memcpy -> pinned slot -> kernel over PCIe on the slot -> memcpy back, spread over kPipes
-//                     independent pipelines (host thread + two slots each, double-buffered): one thread
-//                     copies pageable<->pinned at 22 GB/s, eight at 113 (profiles/r01_ubench_hostpath.txt),
-//                     so the copies hide under the link.  41-43 GB/s at 1-4 GiB with 8 pipelines x 8 MiB
-//                     slots, against 27-30 for the r01 form of this route (memcpy -> H2D DMA -> kernel in HBM ->
-//                     D2H DMA -> memcpy, kept selectable; profiles/r02_sweep_staged_routes.txt).
-//                     A file endpoint replaces its memcpy by pread / pwrite on the pinned slot.
-//   small (<= 1 MiB)  what the reference's three call sites pass (headers): no DMA submissions at
-//                     all, the kernel reads and writes pinned memory across PCIe itself.
+//                     device slots, no host threads.  50.2-50.4 GB/s of payload at 64 MiB .. 4 GiB, each byte
+//                     crossing the link twice.  (Testing flavour, pinned mode 1: chunked H2D -> kernel in HBM ->
+//                     D2H straight from / to the pages through a ring of device slots, 26-29 GB/s.)  When only
+//                     one side of a file stream is pinned memory, that side is DMA'd directly or -- file ->
+//                     page-locked memory -- read into the destination itself and cycled where it lies.
+//   pageable, large   copy -> pinned slot -> kernel across PCIe on the slot -> copy back, spread over kPipes
+//                     independent pipelines (host thread + two slots each, double-buffered), the stream cut into
+//                     ~64 pieces of >= 1 MiB behind a 512 KiB ramp, the kernels queued on 4 shared lanes:
+//                     36.5 / 43.6 / 46.4 / 48.1 GB/s at 16 / 64 / 256 / 1024 MiB.  (Testing flavour, staged mode 1:
+//                     copy -> H2D DMA -> kernel in HBM -> D2H DMA -> copy, round 1's form, 27-30 GB/s.)
+//                     A file endpoint replaces its copy by pread / pwrite on the pinned slot.
+//   small (<= 1 MiB)  what the reference's three call sites pass (headers): one slot, one kernel across PCIe,
+//                     no DMA submissions, no workers.
 //
-// Who runs the pipelines (round 4).  A device's staging context owns a pool of slots and a pool of PARKED worker threads
-// (started on first use, bound to the GPU's NUMA node once, never joined).  A call takes the slots it needs from the pool
-// -- two callers on one GPU run side by side, each on its own slots; a call that finds too few free runs with fewer
-// pipelines, one that finds none waits for a release -- posts its pipelines to the workers and starts pipeline 0 itself
-// at once; workers and caller draw pipeline indices from the call until none is left.  Round 3 spawned (and bound, and
-// joined) seven std::threads per call and held one mutex per device for the length of the call: 0.2-0.3 ms of a 0.9-2.3 ms
-// call at 16-64 MiB, and concurrent callers ran strictly one after the other.  modgpu_host_trace (modgpu_testing.h) records
-// every step of a call with a timestamp; bin/modbench --hostcall --trace prints the timeline.
+// Who runs the pipelines.  A device has one staging context per NUMA node its callers' pages can be on (set 0: next to
+// the GPU); a context owns a pool of slots and a pool of PARKED worker threads (started on first use, bound to the
+// context's node once, never joined).  A call takes the slots it needs from the pool -- two callers on one GPU run side by
+// side, each on its own slots; a call that finds too few free runs with fewer pipelines, one that finds none waits for a
+// release (header-sized calls have two slots of their own) -- posts its pipelines to the workers and starts pipeline 0
+// itself at once; workers and caller draw pipeline indices from the call until none is left.
+//
+// When the GPU is lost in the middle of a call every pipeline stops, waits for what it has in flight, and the host loop
+// finishes exactly the pieces whose result has not reached the destination (Job::done, finish_on_host) -- Cycle cannot fail
+// (CEncryptionCycler.cpp:4-14).  The one case that stays an error is page-locked memory cycled in place by a kernel that
+// died after it was launched.  modgpu_host_trace (modgpu_testing.h) records every step of a call with a timestamp and the
+// thread id; bin/modbench --route ... / --hostcall --trace print the timeline.
 #include <fcntl.h>
 #include <pthread.h>
 #include <sched.h>
@@ -548,7 +551,7 @@ struct Call {
     }
 };
 
-// A parked worker: bound to its GPU's NUMA node and HIP device once, then serves whatever calls post.
+// A parked worker: bound to its staging set's NUMA node and to the HIP device once, then serves whatever calls post.
 void worker_main(Staging *s, int logical, int phys, cpu_set_t allowed, bool have_allowed)
 {
     // a staging worker's copies run where its set's slots are: next to the GPU, or on the node the set was made for
@@ -740,12 +743,10 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
         return MODGPU_OK;
     }
 
-    // slot size: the whole buffer if it is small, else ~n/16 between 4 MiB and the cap (8 MiB by default:
-    // profiles/r02_sweep_staged_routes.txt)
-    // Memory on both sides: the round-4 schedule (~32 chunks of >= 1 MiB, ramped, kernels on shared lanes).  A FILE on either
-    // side keeps round 3's (~16 chunks of >= 4 MiB, all alike, a stream per slot): there the slow stage is pread / pwrite, which
-    // wants few large calls, and an interleaved A/B of both schedules on the file routes had the new one 3-5 % behind
-    // (profiles/r04_file_routes.txt).
+    // slot size: the whole buffer if it is small, else ~n/split between chunk_min and the cap (8 MiB by default).
+    // Memory on both sides, and file -> memory: ~64 chunks of >= 1 MiB, ramped, kernels on shared lanes (profiles/r05_pcie_grid.txt).
+    // Memory -> file and file -> file: ~16 chunks of >= 4 MiB, all alike, a stream per slot -- there the slow stage is pwrite,
+    // which wants few large calls (profiles/r04_file_routes.txt, r05_file_routes.txt).
     const bool mem_both = (src.mem && dst.mem) || (kFileSched != 0 && !src.mem && dst.mem); // (named for what it was: "takes the memory schedule")
     const uint64_t split = mem_both ? kSplit : 16, chunk_min = mem_both ? kChunkMin : std::min<uint64_t>(4ull << 20, kChunk);
     uint64_t chunk = n <= chunk_min ? std::max<uint64_t>(n, 1ull << 20)

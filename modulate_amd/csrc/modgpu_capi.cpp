@@ -54,11 +54,13 @@ int fail_io(const char *what)
 }
 
 // MODGPU_MIN_GPU_BYTES (read once): modgpu_cycle_auto_host serves buffers shorter than this with the host loop.
-// Default: the crossover measured on the MI355X node between the kernel route and ONE host thread
-// (profiles/r03_small_call_crossover.txt).  A kernel launch plus the wait for it costs ~14 us before the first byte
-// moves and the data crosses PCIe twice; the AVX-512 host loop does 17 GB/s per core on that node's EPYC 9575F:
-// a 4 KiB header takes 0.4 us against 16, 512 KiB (the largest header the reference can write, CArk.cpp:911-912)
-// 30 us against 67, and the kernel route first gets ahead of one thread between 16 and 32 MiB.
+// A kernel launch plus the wait for it costs ~14 us before the first byte moves and the data crosses PCIe twice; the AVX-512
+// host loop does 17 GB/s per core on the MI355X node's EPYC 9575F: a 4 KiB header takes 0.4 us against 16, 512 KiB (the
+// largest header the reference can write, CArk.cpp:911-912) 30 us against 44 (profiles/r05_small_call_crossover.txt).  Since
+// round 5's short-launch grid and finer cut the kernel route overtakes ONE host thread at 2 MiB already (it was 16-32 MiB when
+// this default was chosen, r03), but from 4 MiB the host loop runs on several threads and stays ahead up to this size
+// (4 / 8 / 16 MiB: 31 / 60 / 117 GB/s against 22 / 32 / 35), so below it a call is over sooner on the host whichever way one
+// counts; from here up the default policy (below) gives the buffer to the GPU and the cores back to the caller.
 constexpr uint64_t kMinGpuBytesDefault = 16ull << 20;
 uint64_t min_gpu_bytes()
 {
