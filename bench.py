@@ -236,9 +236,11 @@ def main():
                     "frac": round(2.0 * nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         first_pass = {"what": "fresh process, part just uploaded: ONE encrypt launch, HIP events on the launch stream (GB/s = 2*bytes/time)",
                       "part": rate(n, series[0]),
-                      # the chip has been idle for the seconds the upload took: its very first launch also pays the wake-up
-                      # (~50 us); the launch right after it (the undo) shows the size's own rate
+                      # one launch from an IDLE queue: the event pair also holds what lies between the start marker and the kernel's
+                      # first wave (the host's planning and packet write, the chip bringing its shader engines up) -- the dispatch itself
+                      # takes 0.127-0.128 ms here by rocprofv3's timestamps, 0.80-0.81 of peak (profiles/r05_first_launch.txt, run F)
                       "part_411MB": rate(small_n, t_small), "part_411MB_next_launch": rate(small_n, t_small_again),
+                      "part_411MB_note": "events from an idle queue include dispatch latency; the dispatch itself: 0.127-0.128 ms = 0.80-0.81 (profiles/r05_first_launch.txt run F)",
                       "ms_of_launches_1_to_12": [round(x, 4) for x in series],
                       "slowest_of_launches_1_to_12": rate(n, max(series)),
                       "cause_of_the_dip": "shader-clock (DVFS) transient after load onset, not the buffer's state: profiles/r03_first_pass.txt"}

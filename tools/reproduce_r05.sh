@@ -34,7 +34,9 @@ grid)         # profiles/r05_pcie_grid.txt: workgroups of a launch across PCIe, 
 wake)         # profiles/r05_first_launch.txt: the chip's first launch after an upload
     timeout -k 10 200 tools/first_pass wake 411000000 9 1500 > $O/r05_wake_411MB.txt
     timeout -k 10 200 tools/first_pass wake 4294967296 5 1500 > $O/r05_wake_4GiB.txt
-    timeout -k 10 200 tools/first_pass wake 411000000 9 100 > $O/r05_wake_411MB_idle100ms.txt ;;
+    timeout -k 10 200 tools/first_pass wake 411000000 9 100 > $O/r05_wake_411MB_idle100ms.txt
+    timeout -k 10 500 python3 tools/first_launch_where.py 4 > $O/r05_first_launch_where.txt   # run F: events ...
+    bash tools/first_launch_trace.sh ;;                                                        # ... against the dispatches' own timestamps
 lsp)          # profiles/r05_lsp.txt: the next chunk's loads spread over the trip, every row validated
     for n in 4294967296 411000000; do
       TUNE_ONLY="LSP|PRODUCT modgpu_cycle_queue" timeout -k 10 400 tools/tune_cycle $n 9 > $O/r05_lsp_$n.txt
