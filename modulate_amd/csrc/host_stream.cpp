@@ -191,11 +191,25 @@ struct Staging {
 // all processes on a two-socket node.  So a call whose pages live on another node than the GPU takes THAT node's set: slots
 // allocated there, workers bound there; both copies stay inside one socket and only the GPU crosses to the other -- which costs
 // it nothing (one kernel across PCIe on the other socket's memory runs at the same 50 GB/s, profiles/r03_numa.txt).
-constexpr int kNodeSets = 5; // set 0: next to the GPU (also: node unknown, file endpoints); sets 1..4: NUMA nodes 0..3
-Staging *g_staging = new Staging[kMaxDevices * kNodeSets];
-// fork(): the child has neither the parked workers nor a usable HIP context; it starts with fresh, empty staging contexts (the
+constexpr int kNodeSets = 9; // set 0: next to the GPU (also: node unknown, file endpoints, nodes beyond 7); sets 1..8: NUMA nodes 0..7 (two sockets in NPS4)
+// Contexts are made on first use (most processes use one or two of the 576) and never destroyed.
+std::atomic<Staging *> g_staging[kMaxDevices * kNodeSets];
+Staging &staging_of(int dev, int set)
+{
+    std::atomic<Staging *> &at = g_staging[dev * kNodeSets + set];
+    Staging *s = at.load(std::memory_order_acquire);
+    if (!s) {
+        Staging *fresh = new Staging;
+        if (at.compare_exchange_strong(s, fresh, std::memory_order_acq_rel)) s = fresh;
+        else delete fresh; // another caller was first
+    }
+    return *s;
+}
+// fork(): the child has neither the parked workers nor a usable HIP context; it starts with no staging contexts at all (the
 // old ones, whose mutexes a vanished thread may hold, are leaked on purpose).  ADVICE r4.
-const int g_staging_atfork = ::pthread_atfork(nullptr, nullptr, [] { g_staging = new Staging[kMaxDevices * kNodeSets]; });
+const int g_staging_atfork = ::pthread_atfork(nullptr, nullptr, [] {
+    for (auto &p : g_staging) p.store(nullptr, std::memory_order_relaxed);
+});
 std::atomic<uint64_t> g_pool_spawned{0}, g_pool_tasks{0}, g_slot_waits{0}, g_calls_in_flight{0}, g_calls_overlapped{0}, g_node_set_calls{0};
 
 // Slots a call owns, given back (and waiters woken) when the call ends, whichever way.
@@ -670,9 +684,9 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
         }
     }
     const int gpu_node = copy_node >= 0 ? device_numa_node(dev) : -1;
-    const int set = copy_node >= 0 && gpu_node >= 0 && copy_node != gpu_node && have_mask ? 1 + copy_node % (kNodeSets - 1) : 0;
-    Staging &s = g_staging[dev * kNodeSets + set];
-    if (set != 0) { // (every caller of this set writes the same value: the set's index is a function of the node)
+    const int set = copy_node >= 0 && copy_node < kNodeSets - 1 && gpu_node >= 0 && copy_node != gpu_node && have_mask ? 1 + copy_node : 0;
+    Staging &s = staging_of(dev, set);
+    if (set != 0) { // (every caller of this set writes the same value: a set belongs to one node)
         if (s.node.load(std::memory_order_relaxed) != copy_node) s.node.store(copy_node, std::memory_order_relaxed);
         g_node_set_calls.fetch_add(1, std::memory_order_relaxed);
     }
@@ -868,7 +882,7 @@ int modgpu_debug_hold_slots(int device, int count)
     std::lock_guard<std::mutex> lock(mu);
     held[device].reset();
     if (count <= 0) return 0;
-    held[device].reset(new SlotLease(g_staging[device * kNodeSets]));
+    held[device].reset(new SlotLease(staging_of(device, 0)));
     held[device]->acquire(count, 2);
     return (int)held[device]->ids.size();
 }
