@@ -141,7 +141,8 @@ int modgpu_cycle_batch_device(void *const *dev_parts, const uint64_t *sizes, con
 /* Replaces CEncryptionCycler::Cycle (CEncryptionCycler.cpp:4-14) for a caller-owned HOST buffer,
  * on the GPU.  Pageable memory is staged through page-locked slots owned by this library (memcpy ->
  * slot -> kernel across PCIe on the slot -> memcpy back, chunked over several host threads and
- * overlapped); memory from modgpu_host_alloc / modgpu_host_register is cycled where it lies by one
+ * overlapped; below 2 GiB ONE kernel serves the whole call and takes each chunk when its copy in has
+ * landed); memory from modgpu_host_alloc / modgpu_host_register is cycled where it lies by one
  * kernel across PCIe, with no staging copy.  Synchronous: on return host_buf holds the result.
  * Never retains or frees host_buf. */
 int modgpu_cycle_host(uint8_t *host_buf, uint64_t n, int32_t key, uint64_t stream_off, int device);

@@ -74,7 +74,9 @@ enum {
     MODGPU_TRACE_FILL_END = 5, MODGPU_TRACE_LAUNCHED = 6, MODGPU_TRACE_SYNC_BEGIN = 7, MODGPU_TRACE_SYNC_END = 8, MODGPU_TRACE_DRAIN_END = 9,
     MODGPU_TRACE_PIPE_END = 10, MODGPU_TRACE_CALL_END = 11,
     MODGPU_TRACE_FAILED = 12, /* a pipeline met a failure: chunk = the piece, bytes = the stage (MODGPU_STAGE_*) */
-    MODGPU_TRACE_RESCUED = 13 /* the host loop finished the call: chunk = runs of adjacent pieces, bytes = their bytes */
+    MODGPU_TRACE_RESCUED = 13, /* the host loop finished the call: chunk = runs of adjacent pieces, bytes = their bytes */
+    MODGPU_TRACE_READY = 14 /* host-fed call: a pipeline marked its chunk ready for the call's one kernel (what LAUNCHED is per chunk on the other routes;
+                             * the call's single launch is one LAUNCHED event of pipe -1 with the call's bytes) */
 };
 /* enable != 0 clears the buffer and starts recording (at most 2^20 events are kept); 0 stops. */
 void modgpu_host_trace(int enable);
@@ -143,7 +145,9 @@ void modgpu_debug_set_launch(int variant, uint32_t grid_cap);
  * and changes them here at run time -- not while a host-buffer call is in flight.  modgpu_host_tunables / _chunking report them. */
 enum { MODGPU_TUNABLE_ZEROCOPY_BYTES = 0, MODGPU_TUNABLE_RING = 1, MODGPU_TUNABLE_SPLIT = 2, MODGPU_TUNABLE_CHUNK_MIN_BYTES = 3,
        MODGPU_TUNABLE_RAMP_BYTES = 4, MODGPU_TUNABLE_LANES = 5, MODGPU_TUNABLE_NTCOPY = 6,
-       MODGPU_TUNABLE_FILE_SCHED = 7 /* 1 (the shipped rule): file -> memory is cut and queued like a memory-to-memory call; 0: like the other file routes */ };
+       MODGPU_TUNABLE_FILE_SCHED = 7, /* 1 (the shipped rule): file -> memory is cut and queued like a memory-to-memory call; 0: like the other file routes */
+       MODGPU_TUNABLE_FEED = 8,       /* 1 (the shipped rule): pageable memory on both sides is cycled by ONE host-fed kernel per call; 0: a launch per chunk */
+       MODGPU_TUNABLE_FEED_CHUNK_BYTES = 9 /* chunk of a host-fed call (256 KiB; whole 32 KiB pieces) */ };
 void modgpu_debug_set_host_tunable(int which, uint64_t value);
 
 /* The NUMA node the library believes its GPUs hang off (-1 = unknown, -2 = ask sysfs, the default).  Lets a one-node machine
@@ -160,8 +164,9 @@ void modgpu_debug_set_pcie_grid(uint32_t cap);
 void modgpu_debug_set_pinned_mode(int mode);
 
 /* How a staged chunk (pageable memory or a file, copied into a pinned slot) is cycled: 0 = library
- * default (= 2), 1 = H2D -> kernel in HBM -> D2H, 2 = the kernel works on the pinned slot across PCIe
- * (no DMA submissions, no device slot).  Same bytes; tools/sweep_pinned.py times them. */
+ * default (the kernel works on the pinned slot across PCIe -- no DMA submissions, no device slot --, and where both sides
+ * are pageable memory it is ONE host-fed kernel per call, cycle_feed_kernel.h), 1 = H2D -> kernel in HBM -> D2H,
+ * 2 = the kernel on the slot with a launch per chunk everywhere (the default until round 5).  Same bytes. */
 void modgpu_debug_set_staged_mode(int mode);
 
 /* Failure injection: the next `count` host-buffer / file calls fail with MODGPU_ERR_HIP before they touch

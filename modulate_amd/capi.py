@@ -79,7 +79,7 @@ class HostTraceEvent(ctypes.Structure):
 
 
 HOST_TRACE_KINDS = ("call_begin", "slots", "posted", "pipe_start", "fill_begin", "fill_end", "launched", "sync_begin", "sync_end",
-                    "drain_end", "pipe_end", "call_end", "failed", "rescued")
+                    "drain_end", "pipe_end", "call_end", "failed", "rescued", "ready")
 
 
 class LaunchInfo(ctypes.Structure):
@@ -266,7 +266,8 @@ def debug_set_staged_mode(mode=0):
     _debug_lib().modgpu_debug_set_staged_mode(mode)
 
 
-HOST_TUNABLES = {"zerocopy_bytes": 0, "ring": 1, "split": 2, "chunk_min_bytes": 3, "ramp_bytes": 4, "lanes": 5, "ntcopy": 6, "file_sched": 7}
+HOST_TUNABLES = {"zerocopy_bytes": 0, "ring": 1, "split": 2, "chunk_min_bytes": 3, "ramp_bytes": 4, "lanes": 5, "ntcopy": 6, "file_sched": 7,
+                 "feed": 8, "feed_chunk_bytes": 9}
 
 
 def debug_set_host_tunable(name, value):

@@ -277,7 +277,7 @@ int HostCall()
 int HostTrace()
 {
     if( modgpu_device_count() < 1 ) { std::printf( "no HIP device\n" ); return 1; }
-    static const char* kKind[] = { "call_begin", "slots", "posted", "pipe_start", "fill_begin", "fill_end", "launched", "sync_begin", "sync_end", "drain_end", "pipe_end", "call_end", "failed", "rescued" };
+    static const char* kKind[] = { "call_begin", "slots", "posted", "pipe_start", "fill_begin", "fill_end", "launched", "sync_begin", "sync_end", "drain_end", "pipe_end", "call_end", "failed", "rescued", "ready" };
     uint64_t tun[ 4 ], chk[ 4 ];
     modgpu_host_tunables( tun );
     modgpu_host_chunking( chk );
@@ -317,6 +317,7 @@ int HostTrace()
             case MODGPU_TRACE_PIPE_START: p.start = t; break;
             case MODGPU_TRACE_FILL_BEGIN: p.t_fill = t; break;
             case MODGPU_TRACE_FILL_END: p.fill += t - p.t_fill; p.t_launch = t; ++p.chunks; break;
+            case MODGPU_TRACE_READY: // (host-fed call: marking the chunk ready is this route's "launch")
             case MODGPU_TRACE_LAUNCHED: p.launch += t - p.t_launch; if( p.first_launch < 0 ) p.first_launch = t; break;
             case MODGPU_TRACE_SYNC_BEGIN: p.t_sync = t; break;
             case MODGPU_TRACE_SYNC_END: p.sync += t - p.t_sync; p.t_fill = t; break;
@@ -432,7 +433,7 @@ int Route( const std::string& kind, uint64_t mib, int reps )
         if( e.kind == MODGPU_TRACE_LAUNCHED ) std::printf( "launch tid %d call %d pipe %d piece %llu bytes %llu t_us %.1f\n", e.tid, call, e.pipe, (unsigned long long)e.chunk, (unsigned long long)e.bytes, ( e.t_ns - z ) * 1e-3 );
     }
     // the last call in full: what happens before its first kernel and after its last
-    static const char* kKind[] = { "call_begin", "slots", "posted", "pipe_start", "fill_begin", "fill_end", "launched", "sync_begin", "sync_end", "drain_end", "pipe_end", "call_end", "failed", "rescued" };
+    static const char* kKind[] = { "call_begin", "slots", "posted", "pipe_start", "fill_begin", "fill_end", "launched", "sync_begin", "sync_end", "drain_end", "pipe_end", "call_end", "failed", "rescued", "ready" };
     size_t lastBegin = 0;
     for( size_t k = 0; k < ev.size(); ++k ) if( ev[ k ].kind == MODGPU_TRACE_CALL_BEGIN ) lastBegin = k;
     for( size_t k = lastBegin; k < ev.size(); ++k )

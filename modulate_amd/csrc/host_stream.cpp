@@ -54,6 +54,8 @@
 #include <vector>
 
 #include "../../include/modgpu_testing.h"
+#include "cycle_feed_kernel.h"
+#include "lcg.h"
 #include "modgpu_internal.h"
 #include "numa_place.h"
 #include "scalar_path.h"
@@ -149,6 +151,15 @@ constexpr int kFileLanes = 0; // calls with a file on either side keep a stream 
 // file route; with round 5's short-launch grid it is ahead where the destination is memory: 33.8 / 39.7 / 44.1 -> 34.7 / 42.0 / 46.8 GB/s
 // at 64 / 392 / 4096 MiB into page-locked memory, and level (within the file system's noise) the other way (profiles/r05_file_routes.txt).
 MODGPU_KNOB_STORAGE int kFileSched = MODGPU_KNOB("MODGPU_HOST_FILE_SCHED", 1, 0, 1);
+// feed: pageable memory on both sides is cycled by ONE host-fed kernel per call (cycle_feed_kernel.h) instead of a launch per chunk:
+// uniform chunks of feed_chunk bytes (no ramp needed: nothing is launched per chunk), marked ready / done through words in page-locked
+// memory.  profiles/r05_pcie_feed.txt.  0 (and staged mode 2 of the testing flavour): the launch-per-chunk schedule above.
+MODGPU_KNOB_STORAGE int kFeed = MODGPU_KNOB("MODGPU_HOST_FEED", 1, 0, 1);
+MODGPU_KNOB_STORAGE uint64_t kFeedChunk = (uint64_t)MODGPU_KNOB("MODGPU_HOST_FEED_CHUNK_KB", 256, 32, 8192) << 10;
+constexpr uint32_t kFeedChunksMax = 8192;      // ready / done words per call (larger calls take larger chunks)
+constexpr uint64_t kFeedBelow = 2ull << 30;    // from here up a launch per 8 MiB chunk is as good or better (4 GiB: 49.3 against 48.7 GB/s, profiles/r05_pcie_feed.txt)
+constexpr uint32_t kFeedGrid = 32;             // workgroups of the host-fed kernel: what saturates the link (profiles/r05_pcie_persist.txt)
+constexpr uint64_t kFeedPatienceTicks = 200000000ull; // 2 s of the 100 MHz wall clock: a chunk the host has not delivered by then never comes
 
 // ---- host-side timeline of the staged / pinned routes (modgpu_host_trace, reporting only) --------------------------------
 std::atomic<bool> g_trace_on{false};
@@ -183,6 +194,11 @@ struct Staging {
     int workers = 0, parked = 0;                // under mu
     std::atomic<int> node{-1}; // NUMA node this set's slots and workers live on; -1: next to the GPU (where the runtime puts page-locked memory)
     bool placed[kSlots] = {}; // the slot's pinned buffer is our own placed mapping (numa::reserve + hipHostRegister), not hipHostMalloc's
+    // what a host-fed call needs besides its slots, kept with the call's FIRST slot: page-locked host-coherent words
+    // [0, kFeedChunksMax) ready, [kFeedChunksMax, 2 kFeedChunksMax) done, [2 kFeedChunksMax] abort -- and the kernel's device words
+    uint32_t *feed_flags[kSlots] = {};
+    uint32_t *feed_flags_dev[kSlots] = {};
+    uint32_t *feed_work[kSlots] = {};
 };
 // A device has one staging context per NUMA node a caller's pages can be on (round 5, profiles/r05_staged_numa.txt).  The staged
 // route is two CPU copies of every byte, and a copy whose SOURCE is on the other socket runs at 6-12 GB/s per thread instead of 28:
@@ -300,6 +316,22 @@ int staging_reserve(Staging &s, const std::vector<int> &ids, uint64_t need, bool
     return MODGPU_OK;
 }
 
+// The flag words and device counters of a host-fed call (made once per slot that ever leads such a call).
+int feed_reserve(Staging &s, int slot)
+{
+    if (!s.feed_flags[slot]) {
+        uint32_t *h = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h), (2 * kFeedChunksMax + 16) * sizeof(uint32_t), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+        if (hipHostGetDevicePointer(reinterpret_cast<void **>(&s.feed_flags_dev[slot]), h, 0) != hipSuccess) {
+            (void)hipHostFree(h);
+            return fail(MODGPU_ERR_HIP, "hipHostGetDevicePointer (host-fed kernel's flag words)");
+        }
+        s.feed_flags[slot] = h;
+    }
+    if (!s.feed_work[slot]) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.feed_work[slot]), (kFeedChunksMax + 2) * sizeof(uint32_t)));
+    return MODGPU_OK;
+}
+
 // ---- the staging copies ------------------------------------------------------------------------------------------------------
 // What bounds the staged route since round 4 is its two CPU copies of every byte (profiles/r04_staged_midsize.txt): ~10 GB/s per
 // thread, because both are DRAM-miss streams -- and a plain memcpy of a few MiB also READS every destination line before it
@@ -380,6 +412,10 @@ struct Job {
     std::unique_ptr<std::atomic<uint8_t>[]> done; // per piece: its result is in the destination, whole
     std::vector<hipStream_t> lanes; // kernels across PCIe are queued on these in launch order (empty: each on its slot's stream)
     std::atomic<uint64_t> launched{0};
+    // host-fed call (cycle_feed_kernel.h): one kernel for the whole call; a pipeline marks a chunk ready instead of launching, and polls its done word
+    bool feed = false;
+    uint32_t *feed_ready = nullptr, *feed_done = nullptr, *feed_abort = nullptr; // host addresses
+    hipStream_t feed_stream = nullptr;
     int copy_node = -1; // NUMA node the caller's pages live on (-1: unknown, or no pageable memory endpoint): picks the staging set (g_staging)
     cpu_set_t caller_mask; // the calling thread's affinity mask: a worker is never put on a CPU the caller may not use
     bool have_mask = false;
@@ -412,6 +448,28 @@ std::vector<Piece> cut_stream(uint64_t n, uint64_t chunk, int pipes, uint64_t ra
 
 constexpr int kStopped = -1000; // run_pipe: another pipeline of the call failed and this one stopped early -- not an error of its own
 
+// Waits until the host-fed kernel has marked chunk c done.  Spins (the wait is tens of microseconds while the call is healthy), and every
+// ~50 us looks at the rest of the world: a sibling pipeline that failed, and the kernel's stream -- a kernel that has ended without
+// finishing the chunk gave up (it waited too long for the host) or died, and either way the chunk will never be done by it.
+int feed_wait(Job &j, uint64_t c)
+{
+    uint32_t spins = 0;
+    while (__atomic_load_n(&j.feed_done[c], __ATOMIC_ACQUIRE) == 0u) {
+        _mm_pause();
+        if ((++spins & 1023u) != 0) continue;
+        if (j.failed.load(std::memory_order_acquire)) return kStopped;
+        const hipError_t q = hipStreamQuery(j.feed_stream);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            continue;
+        }
+        if (__atomic_load_n(&j.feed_done[c], __ATOMIC_ACQUIRE) != 0u) break; // (it finished the chunk and then ended)
+        return q == hipSuccess ? fail(MODGPU_ERR_HIP, "the host-fed kernel ended before the chunk was done (it gave up waiting for the host)")
+                               : fail_hip(q, "hipStreamQuery (host-fed kernel)");
+    }
+    return MODGPU_OK;
+}
+
 // One pipeline: chunks first, first+stride, ... of the stream through the `ring` slots slots[0..ring).
 // A pinned memory endpoint is DMA'd directly; anything else passes through the slot's pinned buffer.
 // Failure: the pipeline that meets it raises j.failed, every pipeline sees that at its next step and stops; each waits for what
@@ -439,6 +497,7 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
 #define MODGPU_INJECT(piece, stage)                                                                                              \
     do {                                                                                                                         \
         if (injected_at((piece), n_chunks, (stage))) {                                                                           \
+            j.failed.store(true, std::memory_order_release); /* (before the trace line: what follows it in the log has seen it) */ \
             trace(MODGPU_TRACE_FAILED, pipe, (piece), (uint64_t)(stage));                                                        \
             return fail(MODGPU_ERR_HIP, "injected failure (modgpu_debug_inject_failure_at)");                                    \
         }                                                                                                                        \
@@ -452,7 +511,10 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
             span(c, &off, &len);
             trace(MODGPU_TRACE_SYNC_BEGIN, pipe, c, len);
             MODGPU_INJECT(c, MODGPU_STAGE_SYNC);
-            if (on_lanes) HIP_TRY(hipEventSynchronize(s.event[slot]));
+            if (j.feed) {
+                const int rc = feed_wait(j, c);
+                if (rc) return rc;
+            } else if (on_lanes) HIP_TRY(hipEventSynchronize(s.event[slot]));
             else HIP_TRY(hipStreamSynchronize(s.stream[slot]));
             trace(MODGPU_TRACE_SYNC_END, pipe, c, len);
             if (!dst_direct && !j.in_dst) {
@@ -489,6 +551,11 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
                 if (rc) return rc;
                 trace(MODGPU_TRACE_FILL_END, pipe, c, len);
                 MODGPU_INJECT(c, MODGPU_STAGE_LAUNCH);
+                if (j.feed) { // the kernel is there already, waiting for exactly this
+                    __atomic_store_n(&j.feed_ready[c], 1u, __ATOMIC_RELEASE);
+                    trace(MODGPU_TRACE_READY, pipe, c, len);
+                    return MODGPU_OK;
+                }
                 void *mapped = nullptr;
                 HIP_TRY(hipHostGetDevicePointer(&mapped, s.pinned[slot], 0));
                 rc = launch_across_pcie(mapped, len, off, slot);
@@ -522,6 +589,10 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
     if (rc != MODGPU_OK) { // nothing of this call may still be running against the caller's memory (or its slots) once we return
         if (rc != kStopped) j.failed.store(true, std::memory_order_release);
         const std::string keep = t_err;
+        if (j.feed) { // the kernel leaves at its next look at the flag; chunks it has not finished stay undone
+            __atomic_store_n(j.feed_abort, 1u, __ATOMIC_RELEASE);
+            (void)hipStreamSynchronize(j.feed_stream);
+        }
         for (int k = 0; k < ring; ++k) (void)hipStreamSynchronize(s.stream[slots[k]]);
         for (hipStream_t st : j.lanes) (void)hipStreamSynchronize(st);
         (void)hipGetLastError();
@@ -766,6 +837,16 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     uint64_t chunk = n <= chunk_min ? std::max<uint64_t>(n, 1ull << 20)
                                     : std::min<uint64_t>(kChunk, std::max<uint64_t>(chunk_min, ((n / split) + 0xFFFFF) & ~0xFFFFFull));
     chunk = std::min<uint64_t>(chunk, kChunk);
+    // Pageable memory on both sides: ONE host-fed kernel for the whole call (cycle_feed_kernel.h).  Uniform chunks -- as small as the
+    // flag words allow, since no chunk costs a launch -- of whole pieces; a call too large for that (or staged mode 1 / 2 of the testing
+    // flavour, or feed switched off) keeps the launch-per-chunk schedule.
+    bool feed = kFeed != 0 && staged_mode() == 0 && src.mem && dst.mem && !src_direct && !dst_direct && !identity;
+    if (feed) {
+        const uint64_t piece = kFeedPieceBytes;
+        const uint64_t c = std::max<uint64_t>((kFeedChunk + piece - 1) / piece * piece, ((n + kFeedChunksMax - 1) / kFeedChunksMax + piece - 1) / piece * piece);
+        if (c > kChunk || (n + piece - 1) / piece >= kFeedPiecesMax || n >= kFeedBelow) feed = false;
+        else chunk = c;
+    }
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
     Job job(src, dst, n, chunk, key, stream_off);
     // Default routes (profiles/r03_file_routes.txt): pageable memory and files are copied / read into a pinned slot and
@@ -773,6 +854,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     // where it lies; page-locked caller memory that ends in a file is DMA'd.  (Testing flavour, staged mode 1: the DMA
     // form -- H2D, kernel in HBM, D2H -- of the first two.)
     job.slot_kernel = !src_direct && !dst_direct && staged_mode() != 1;
+    job.feed = feed;
     job.in_dst = dst_direct && !src.mem && !identity && staged_mode() != 1;
     int pipes, ring;
     if (all_direct && src.mem && dst.mem) { // no host work at all: one thread keeps a ring of slots busy
@@ -790,15 +872,47 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     SlotLease lease(s);
     lease.acquire(pipes * ring, ring);
     pipes = (int)lease.ids.size() / ring;
-    job.set_plan(cut_stream(n, chunk, pipes, mem_both ? kRamp : 0));
+    job.set_plan(cut_stream(n, chunk, pipes, mem_both && !feed ? kRamp : 0));
     job.copy_node = copy_node;
     job.have_mask = have_mask;
     if (have_mask) job.caller_mask = caller_mask;
-    for (int k = 0; k < (mem_both ? kLanes : kFileLanes) && k < (int)lease.ids.size(); ++k) job.lanes.push_back(nullptr); // (streams exist after staging_reserve)
+    for (int k = 0; k < (feed ? 0 : mem_both ? kLanes : kFileLanes) && k < (int)lease.ids.size(); ++k) job.lanes.push_back(nullptr); // (streams exist after staging_reserve)
     trace(MODGPU_TRACE_SLOTS, -1, (uint64_t)pipes, chunk);
     rc = staging_reserve(s, lease.ids, chunk, !job.slot_kernel && !job.in_dst, !(src_direct && dst_direct) && !job.in_dst);
     if (rc) return rc;
     for (size_t k = 0; k < job.lanes.size(); ++k) job.lanes[k] = s.stream[lease.ids[k]];
+    if (feed) { // the call's one launch: flags and counters cleared, then the kernel, which waits for the pipelines' first chunks
+        const int lead_slot = lease.ids[0];
+        rc = feed_reserve(s, lead_slot);
+        if (rc) return rc;
+        const uint64_t chunks = job.plan.size();
+        uint32_t *const flags = s.feed_flags[lead_slot];
+        std::memset(flags, 0, chunks * sizeof(uint32_t));
+        std::memset(flags + kFeedChunksMax, 0, chunks * sizeof(uint32_t));
+        flags[2 * kFeedChunksMax] = 0;
+        job.feed_ready = flags;
+        job.feed_done = flags + kFeedChunksMax;
+        job.feed_abort = flags + 2 * kFeedChunksMax;
+        job.feed_stream = s.stream[lead_slot];
+        CycleFeedArgs a{};
+        for (int k = 0; k < pipes * ring; ++k) HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&a.slot[k]), s.pinned[lease.ids[(size_t)k]], 0));
+        a.ready = s.feed_flags_dev[lead_slot];
+        a.done = s.feed_flags_dev[lead_slot] + kFeedChunksMax;
+        a.abort = s.feed_flags_dev[lead_slot] + 2 * kFeedChunksMax;
+        a.work = s.feed_work[lead_slot];
+        a.n = n;
+        a.patience_ticks = kFeedPatienceTicks;
+        a.chunk_bytes = (uint32_t)chunk;
+        a.pipes = (uint32_t)pipes;
+        a.base = lcg::state_residue(lcg::key_residue(key), stream_off);
+        const uint32_t pieces = (uint32_t)((n + kFeedPieceBytes - 1) / kFeedPieceBytes);
+        const uint32_t grid = std::min<uint32_t>(kFeedGrid, pieces);
+        HIP_TRY(hipMemsetAsync(a.work, 0, (chunks + 2) * sizeof(uint32_t), job.feed_stream));
+        const hipError_t e = modgpu_launch_cycle_feed(a, grid, job.feed_stream);
+        if (e != hipSuccess) return fail_hip(e, "cycle kernel launch (host-fed)"); // nothing of the caller's has been touched
+        note_feed_launch(grid, n);
+        trace(MODGPU_TRACE_LAUNCHED, -1, 0, n);
+    }
 
     if (pipes <= 1) {
         rc = run_pipe(s, lease.ids.data(), ring, job, 0, 1);
@@ -820,6 +934,19 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
             }
     }
     outcome.touched = job.touched.load();
+    if (feed) {
+        if (rc == MODGPU_OK) {
+            // every chunk is done and drained: the kernel has drawn its last ticket and leaves by itself.  (An error here cannot undo the
+            //  result, which is whole in the destination: it is cleared, and the next call on this device meets whatever is wrong with it.)
+            if (hipStreamSynchronize(job.feed_stream) != hipSuccess) (void)hipGetLastError();
+        } else { // whichever pipeline failed has told the kernel to leave and waited for it; make sure before the slots go back
+            __atomic_store_n(job.feed_abort, 1u, __ATOMIC_RELEASE);
+            const std::string keep = t_err;
+            (void)hipStreamSynchronize(job.feed_stream);
+            (void)hipGetLastError();
+            t_err = keep;
+        }
+    }
     if (rc == MODGPU_OK) {
         account();
         return rc;
@@ -899,6 +1026,8 @@ void modgpu_debug_set_host_tunable(int which, uint64_t value)
     case MODGPU_TUNABLE_LANES: kLanes = (int)clamp(value, 0, 8); break;
     case MODGPU_TUNABLE_NTCOPY: kNtCopy = value != 0; break;
     case MODGPU_TUNABLE_FILE_SCHED: kFileSched = value != 0; break;
+    case MODGPU_TUNABLE_FEED: kFeed = value != 0; break;
+    case MODGPU_TUNABLE_FEED_CHUNK_BYTES: kFeedChunk = clamp(value, 32ull << 10, 8ull << 20); break;
     default: break;
     }
 }

@@ -17,6 +17,7 @@
 
 #include "../../include/modgpu_testing.h"
 #include "crossover_table.h"
+#include "cycle_feed_kernel.h"
 #include "cycle_kernel.h"
 #include "lcg.h"
 #include "modgpu_internal.h"
@@ -603,6 +604,12 @@ int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_of
     t_last_launch = {modgpu_variant_kernel_name(p.variant), p.variant, p.grid, modgpu_variant_block(p.variant),
                      modgpu_variant_chunk_bytes(p.variant), n, p.grid};
     return MODGPU_OK;
+}
+
+void note_feed_launch(uint32_t grid, uint64_t bytes)
+{
+    g_stats.gpu_launches.fetch_add(1, std::memory_order_relaxed);
+    t_last_launch = {modgpu_feed_kernel_name(), CYCLE_FEED, grid, modgpu_feed_block(), kFeedPieceBytes, bytes, grid};
 }
 
 // n_parts buffers resident on the CURRENT device, each its own Cycle call (keystream from offs[i], or 0), asynchronous on

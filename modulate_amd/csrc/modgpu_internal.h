@@ -87,6 +87,8 @@ bool gpu_required(); // MODGPU_REQUIRE_GPU=1 at load
 // ---- page-locked host memory ----------------------------------------------------------------
 // true if [p, p+n) lies inside one allocation of modgpu_host_alloc that is really page-locked.
 bool host_range_pinned(const void *p, uint64_t n);
+// a host-fed launch has happened on the calling thread (host_stream.cpp): path stats and modgpu_last_launch
+void note_feed_launch(uint32_t grid, uint64_t bytes);
 
 // ---- host-buffer / file endpoints (host_stream.cpp) ---------------------------------------
 // Where a stream's bytes come from / go to: caller memory, or a file read / written at offsets

@@ -47,6 +47,7 @@ hipError_t hipHostUnregister(void *p);
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipStreamQuery(hipStream_t s);
 hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus *st);
 hipError_t hipThreadExchangeStreamCaptureMode(hipStreamCaptureMode *m);
 hipError_t hipMemset(void *p, int v, size_t n);

@@ -5,10 +5,12 @@
 // host's planning (splits, jump-ahead states, alignment lead) as well as its memory and thread discipline.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <thread>
 
+#include "../../modulate_amd/csrc/cycle_feed_kernel.h"
 #include "../../modulate_amd/csrc/cycle_kernel.h"
 #include "../../modulate_amd/csrc/lcg.h"
 
@@ -86,6 +88,49 @@ hipError_t modgpu_launch_cycle_queue(const CycleQueueArgs &a, uint32_t, hipStrea
     shim::enqueue(stream, run_batch, new CycleQueueArgs(a));
     return hipSuccess;
 }
+// the host-fed kernel: the same protocol on the stream's thread -- chunk after chunk, wait for `ready` (or `abort`, or patience), cycle the
+// chunk in its slot from the launch arguments alone, mark it `done`.  Runs WHILE the library's pipelines copy in and out, as the kernel does.
+namespace {
+std::atomic<unsigned long long> g_feed_launches{0}, g_feed_gave_up{0};
+void run_feed(void *arg)
+{
+    CycleFeedArgs *a = static_cast<CycleFeedArgs *>(arg);
+    const uint64_t chunks = (a->n + a->chunk_bytes - 1) / a->chunk_bytes;
+    bool gave_up = false;
+    for (uint64_t c = 0; c < chunks && !gave_up; ++c) {
+        const auto since = std::chrono::steady_clock::now();
+        while (std::atomic_ref<const uint32_t>(a->ready[c]).load(std::memory_order_acquire) == 0u) {
+            const double waited_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - since).count();
+            if (std::atomic_ref<const uint32_t>(*a->abort).load(std::memory_order_acquire) != 0u || waited_s * 1e8 > (double)a->patience_ticks) {
+                gave_up = true;
+                break;
+            }
+            std::this_thread::yield();
+        }
+        if (gave_up) break;
+        const uint64_t pos = c * a->chunk_bytes, len = std::min<uint64_t>(a->chunk_bytes, a->n - pos);
+        uint8_t *slot = a->slot[(c % a->pipes) * 2 + (c / a->pipes) % 2];
+        span(slot, len, lcg::mulmod(a->base, lcg::powmod(lcg::A, pos % lcg::PERIOD)));
+        std::atomic_ref<uint32_t>(a->done[c]).store(1u, std::memory_order_release);
+    }
+    if (gave_up) {
+        g_feed_gave_up.fetch_add(1);
+        std::atomic_ref<uint32_t>(a->work[1]).fetch_add(1u);
+    }
+    g_feed_launches.fetch_add(1);
+    delete a;
+}
+} // namespace
+uint32_t modgpu_feed_block() { return 256u; }
+const char *modgpu_feed_kernel_name() { return "shim feed"; }
+hipError_t modgpu_launch_cycle_feed(const CycleFeedArgs &a, uint32_t, hipStream_t stream)
+{
+    shim::enqueue(stream, run_feed, new CycleFeedArgs(a));
+    return hipSuccess;
+}
+extern "C" unsigned long long modgpu_shim_feed_launches(void) { return g_feed_launches.load(); }
+extern "C" unsigned long long modgpu_shim_feed_gave_up(void) { return g_feed_gave_up.load(); }
+
 extern "C" unsigned long long modgpu_shim_batch_launches(void) { return g_batch_launches.load(); }
 extern "C" unsigned long long modgpu_shim_batch_plan_errors(void) { return g_batch_plan_errors.load(); }
 

@@ -43,6 +43,11 @@ struct ShimStream {
         }
         cv.notify_one();
     }
+    bool is_idle()
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        return q.empty() && !busy;
+    }
     void drain()
     {
         std::unique_lock<std::mutex> lock(mu);
@@ -138,6 +143,7 @@ hipError_t hipHostUnregister(void *) { return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new ShimStream; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s) { resolve(s)->drain(); return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t s) { return resolve(s)->is_idle() ? hipSuccess : hipErrorNotReady; }
 hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus *st) { *st = hipStreamCaptureStatusNone; return hipSuccess; }
 hipError_t hipThreadExchangeStreamCaptureMode(hipStreamCaptureMode *) { return hipSuccess; }
 hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t s) { resolve(s)->push(run_copy, new CopyJob{p, nullptr, n, v, true}); return hipSuccess; }

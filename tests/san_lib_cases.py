@@ -28,6 +28,8 @@ def lib():
     L.modgpu_shim_launches.restype = ctypes.c_ulonglong
     L.modgpu_shim_batch_launches.restype = ctypes.c_ulonglong
     L.modgpu_shim_batch_plan_errors.restype = ctypes.c_ulonglong
+    L.modgpu_shim_feed_launches.restype = ctypes.c_ulonglong
+    L.modgpu_shim_feed_gave_up.restype = ctypes.c_ulonglong
     return L
 
 
@@ -46,6 +48,8 @@ def hooks(lib):
             M.debug_inject_failures(0)
             M.debug_inject_failure_at(0, -1)
             M.debug_set_gpu_node(-2)
+            M.debug_set_host_tunable("feed", 1)
+            M.debug_set_host_tunable("feed_chunk_bytes", 256 << 10)
 
 
 def want(pt, key, off=0):
@@ -164,7 +168,7 @@ def test_staged_pipelines_and_routes(hooks):
     assert np.array_equal(M.cycle_host(z.copy(), M.KEY_PS3, stream_off=big_off), want(z, M.KEY_PS3, big_off))
     for n in (1, 4097, (1 << 20) + 1, (3 << 20) - 1, (17 << 20) + 5):
         pt = O.splitmix_bytes(n + 16, n)
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             M.debug_set_staged_mode(mode)
             buf = pt.copy()
             M.cycle_host(buf[9:9 + n], M.KEY_PS3, stream_off=77)
@@ -190,6 +194,31 @@ def test_staged_pipelines_and_routes(hooks):
     M.host_unregister(buf)
     assert np.array_equal(buf, want(pt, M.KEY_PS4))
     assert M.lib().modgpu_host_free(buf.ctypes.data) == 1 and M.lib().modgpu_host_unregister(buf.ctypes.data) == 1
+
+
+def test_host_fed_kernel_route(hooks, lib):
+    """Pageable memory on both sides: ONE host-fed kernel per call (cycle_feed_kernel.h) -- the stand-in runs the same ready / done /
+    abort protocol on the stream's thread while the library's pipelines copy in and out.  Ragged ends (a short last piece, a tail that
+    is not a whole word), one-chunk calls, 32 KiB chunks (many flags), stream offsets; the launch-per-chunk schedule when switched off."""
+    before = lib.modgpu_shim_feed_launches()
+    cases = [((1 << 20) + 1, 0), ((1 << 20) + 16, 7), ((2 << 20) + 4097, (1 << 40) + 3), ((3 << 20) - 1, 5), ((9 << 20) + 15, 0), (5 << 20, 123456789)]
+    for chunk in (256 << 10, 32 << 10, 1 << 20):
+        M.debug_set_host_tunable("feed_chunk_bytes", chunk)
+        for n, off in cases:
+            pt = O.splitmix_bytes(n + 32, n ^ chunk)
+            buf = pt.copy()
+            M.cycle_host(buf[7:7 + n], M.KEY_PS4, stream_off=off)
+            w = pt.copy()
+            O.cycle_at(w[7:7 + n], M.KEY_PS4, off)
+            assert np.array_equal(buf, w), (chunk, n, off)
+            assert M.last_launch()["variant"] == 4 and M.last_launch()["grid"] <= 32
+    made = lib.modgpu_shim_feed_launches() - before
+    assert made == 3 * len(cases) and lib.modgpu_shim_feed_gave_up() == 0
+    M.debug_set_host_tunable("feed", 0)
+    pt = O.splitmix_bytes((5 << 20) + 3, 3)
+    assert np.array_equal(M.cycle_host(pt.copy(), M.KEY_PS4), want(pt, M.KEY_PS4))
+    assert lib.modgpu_shim_feed_launches() - before == made  # a launch per chunk, as until round 5
+    M.debug_set_host_tunable("feed", 1)
 
 
 def test_concurrent_callers_share_one_device_and_the_parked_workers(hooks):

@@ -515,7 +515,7 @@ def test_environment_of_the_shipped_library_is_what_the_header_lists():
                                  "MODGPU_NUMA", "MODGPU_HELPER_BELOW_MHZ", "MODGPU_HOST_PIPES", "MODGPU_HOST_CHUNK_MB"}, (sorted(shipped), sorted(listed))
     testing = names(os.path.join(ROOT, "modulate_amd", "libmodgpu_testing.so"))
     assert testing - shipped == {"MODGPU_HOST_ZEROCOPY_KB", "MODGPU_HOST_RING", "MODGPU_HOST_SPLIT", "MODGPU_HOST_CHUNK_MIN_MB", "MODGPU_HOST_RAMP_KB", "MODGPU_HOST_LANES",
-                                  "MODGPU_HOST_NTCOPY", "MODGPU_HOST_FILE_SCHED", "MODGPU_HOST_SPREAD", "MODGPU_HOST_CGROUP"}, sorted(testing - shipped)
+                                  "MODGPU_HOST_NTCOPY", "MODGPU_HOST_FILE_SCHED", "MODGPU_HOST_FEED", "MODGPU_HOST_FEED_CHUNK_KB", "MODGPU_HOST_SPREAD", "MODGPU_HOST_CGROUP"}, sorted(testing - shipped)
     code = ("import json, modulate_amd as M; a = [M.host_tunables(), M.host_chunking()]; M.use_testing_flavour(); "
             "print('T', json.dumps([a, [M.host_tunables(), M.host_chunking()]]))")
     e = {k: v for k, v in os.environ.items() if not k.startswith("MODGPU_HOST_")}

@@ -204,6 +204,55 @@ def test_staged_dma_route(gpu_t, oracle):
         gpu.debug_set_staged_mode(0)
 
 
+def test_staged_launch_per_chunk_route(gpu_t, oracle):
+    """The kernel on the slot with a LAUNCH PER CHUNK (the pageable route's schedule until round 5, still what a file endpoint and a
+    call of 2 GiB or more take): forced for pageable memory, same bytes."""
+    gpu = gpu_t
+    gpu.debug_set_staged_mode(2)
+    try:
+        for n in (HOST_PATH_SIZES[0], HOST_PATH_SIZES[3]):
+            pt = oracle.splitmix_bytes(n, n)
+            ct = gpu.cycle_host(pt.copy(), 0x90CFC0AB, stream_off=77)
+            want = pt.copy()
+            oracle.cycle_at(want, 0x90CFC0AB, 77)
+            assert np.array_equal(ct, want), n
+            assert "feed" not in gpu.last_launch()["kernel"]
+    finally:
+        gpu.debug_set_staged_mode(0)
+
+
+def test_host_fed_kernel_route(gpu_t, oracle):
+    """Pageable memory on both sides: ONE host-fed kernel per call (cycle_feed_kernel.h), chunks marked ready / done through words in
+    page-locked memory.  Ragged ends -- a short last piece, a tail that is not a whole 16-byte word, a call of one or two chunks --,
+    misaligned buffers, stream offsets up to 2^64, 32 KiB ... 1 MiB chunks (many flags / few), twice = the plaintext again; and the
+    launch the library reports is that kernel, once per call."""
+    gpu = gpu_t
+    cases = [((1 << 20) + 1, 0), ((1 << 20) + 16, 7), ((2 << 20) + 4097, (1 << 40) + 3), ((3 << 20) - 1, (1 << 64) - 70000), ((9 << 20) + 15, 0),
+             (5 << 20, 123456789), ((33 << 20) + 32767, 5), ((64 << 20) + 32769, 0)]
+    try:
+        for chunk in (256 << 10, 32 << 10, 1 << 20):
+            gpu.debug_set_host_tunable("feed_chunk_bytes", chunk)
+            for n, off in cases:
+                pt = oracle.splitmix_bytes(n + 64, n ^ chunk)
+                buf = pt.copy()
+                before = gpu.path_stats()["gpu_launches"]
+                gpu.cycle_host(buf[13:13 + n], 0xC64EED30, stream_off=off)
+                ll = gpu.last_launch()
+                assert ll["kernel"] == "modgpu_cycle_feed_kernel" and ll["variant"] == 4 and ll["grid"] <= 32 and gpu.path_stats()["gpu_launches"] == before + 1, ll
+                want = pt.copy()
+                oracle.cycle_at(want[13:13 + n], 0xC64EED30, off)
+                assert np.array_equal(buf, want), (chunk, n, off, int(np.flatnonzero(buf != want)[0]))
+                gpu.cycle_host(buf[13:13 + n], 0xC64EED30, stream_off=off)
+                assert np.array_equal(buf, pt)
+        gpu.debug_set_host_tunable("feed", 0)
+        pt = oracle.splitmix_bytes((5 << 20) + 3, 3)
+        assert np.array_equal(gpu.cycle_host(pt.copy(), 0xC64EED30), oracle.cycle(pt.copy(), 0xC64EED30))
+        assert "feed" not in gpu.last_launch()["kernel"]
+    finally:
+        gpu.debug_set_host_tunable("feed", 1)
+        gpu.debug_set_host_tunable("feed_chunk_bytes", 256 << 10)
+
+
 def test_parts_sharding_host(gpu, oracle):
     sizes = [0, 1, 4096, 1_000_003, (8 << 20) + 5, 77]
     parts = [oracle.splitmix_bytes(s, 100 + i) for i, s in enumerate(sizes)]

@@ -44,7 +44,7 @@ def _san_lib_cases(preload, lib, extra_env):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "san_lib_cases.py"), "-x", "-q", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=ROOT, timeout=1500)
-    assert r.returncode == 0 and "12 passed" in r.stdout, r.stdout[-4000:] + r.stderr[-4000:]
+    assert r.returncode == 0 and "13 passed" in r.stdout, r.stdout[-4000:] + r.stderr[-4000:]
 
 
 def test_library_host_code_under_asan_ubsan():

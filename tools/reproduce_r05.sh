@@ -7,7 +7,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 case "${1:-help}" in
 build)        # on the build box (cross-compiles without a GPU); the binaries travel with the snapshot
-    make -s -C modulate_amd/csrc all && make -s -C tools tune_cycle ubench_queue_rw first_pass ubench_pcie_bidir ;;
+    make -s -C modulate_amd/csrc all && make -s -C tools tune_cycle ubench_queue_rw first_pass ubench_pcie_bidir ubench_pcie_persist ;;
 pcie)         # profiles/r05_pcie_route_*.json: rocprofv3 under the routes host-resident data really takes.
               # The program stands directly behind `--` (no env / shell hop under the profiler).
     TAG=${2:-r05}
@@ -28,6 +28,10 @@ pcie)         # profiles/r05_pcie_route_*.json: rocprofv3 under 
     find $D -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_pcie_route_config4_kernel_stats.csv
     find $D -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_pcie_route_config4_kernel_trace.csv
     rm -rf $D ;;
+feed)         # profiles/r05_pcie_persist.txt, r05_pcie_feed.txt, r05f_pcie_route_staged_*: one host-fed kernel per pageable call
+    for m in 64 16 256 1024; do timeout -k 10 100 taskset -c 64-127,192-255 tools/ubench_pcie_persist $m 12 >> $O/r05_persist.txt; done
+    timeout -k 10 300 taskset -c 64-127,192-255 python3 tools/ab_feed.py 10 > $O/r05_ab_feed.txt
+    bash tools/profile_feed.sh ;;
 grid)         # profiles/r05_pcie_grid.txt: workgroups of a launch across PCIe, lanes, and how a staged stream is cut
     timeout -k 10 420 python3 tools/sweep_pcie_grid.py grid > $O/r05_sweep_grid.txt
     timeout -k 10 300 python3 tools/sweep_pcie_grid.py cut > $O/r05_sweep_cut.txt ;;
