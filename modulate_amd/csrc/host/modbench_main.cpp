@@ -15,7 +15,7 @@
 //       when the slots were there, when each pipeline started, and per pipeline what its time went into -- filling slots
 //       (memcpy in), waiting for kernels, draining slots (memcpy out); full event list for the 64 MiB call.  Then two
 //       callers at once on one GPU (64 MiB each) against one caller alone.
-//   modbench --route pinned|staged --mib N [--reps R]
+//   modbench --route pinned|staged --mib N [--reps R] [--socket near|far]
 //       R calls of modgpu_cycle_host over ONE buffer of N MiB -- page-locked (modgpu_host_alloc: cycled in place by one kernel
 //       across PCIe) or pageable (the staged route) -- with the host-side timeline on for the whole run.  Prints every call's wall
 //       time and, one line each, every kernel launch the library made (thread id, call, pipeline, piece, bytes): run under
@@ -30,6 +30,7 @@
 //       pread / pwrite schedule with the cipher skipped (I/O only) and the cipher with the I/O skipped (GPU only).
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sched.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -377,9 +378,39 @@ int HostTrace()
 
 // ---- --route: one host-buffer route, R calls, every launch listed (to be joined with a rocprofv3 kernel trace) -------------------
 uint64_t gRouteOffset = 4; // --offset K: the buffer starts K bytes behind a page boundary (the reference's callers pass buf + 4)
+std::string gRouteSocket;  // --socket near|far: this thread (and so the pages it touches) on the GPU's NUMA node / on another one, before anything
+                           // is allocated -- a profile that does not depend on where the scheduler happened to start the process
+void BindToSocket( const std::string& which )
+{
+    const int gpuNode = modgpu_device_numa_node( 0 );
+    if( gpuNode < 0 ) { std::printf( "--socket %s: the GPU's NUMA node is unknown, not bound\n", which.c_str() ); return; }
+    for( int node = 0; node < 64; ++node )
+    {
+        if( ( which == "near" ) != ( node == gpuNode ) ) continue;
+        std::FILE* f = std::fopen( ( "/sys/devices/system/node/node" + std::to_string( node ) + "/cpulist" ).c_str(), "r" );
+        if( !f ) continue;
+        char text[ 4096 ] = {};
+        const size_t got = std::fread( text, 1, sizeof text - 1, f );
+        std::fclose( f );
+        cpu_set_t now, want;
+        CPU_ZERO( &want );
+        if( !got || sched_getaffinity( 0, sizeof now, &now ) != 0 ) continue;
+        int count = 0;
+        for( char* p = text; *p && *p != '\n'; )
+        {
+            const long a = std::strtol( p, &p, 10 );
+            const long b = *p == '-' ? std::strtol( p + 1, &p, 10 ) : a;
+            for( long c = a; c <= b && c < CPU_SETSIZE; ++c ) if( CPU_ISSET( c, &now ) ) { CPU_SET( c, &want ); ++count; }
+            if( *p == ',' ) ++p;
+        }
+        if( count && sched_setaffinity( 0, sizeof want, &want ) == 0 ) return;
+    }
+    std::printf( "--socket %s: no such node with CPUs this process may use, not bound\n", which.c_str() );
+}
 int Route( const std::string& kind, uint64_t mib, int reps )
 {
     if( modgpu_device_count() < 1 ) { std::printf( "no HIP device\n" ); return 1; }
+    if( !gRouteSocket.empty() ) BindToSocket( gRouteSocket );
     const uint64_t n = mib << 20;
     const bool pinned = kind == "pinned";
     void* mem = nullptr;
@@ -687,6 +718,7 @@ int main( int argc, char** argv )
         else if( a == "--route" ) { mode = "route"; route = next(); }
         else if( a == "--mib" ) routeMib = std::strtoull( next(), nullptr, 0 );
         else if( a == "--offset" ) gRouteOffset = std::strtoull( next(), nullptr, 0 ) & 4095;
+        else if( a == "--socket" ) gRouteSocket = next();
         else if( a == "--reps" ) routeReps = std::max( 1, std::atoi( next() ) );
         else if( a == "--alloc" ) { mode = "alloc"; partBytes = 3291444381ull; nParts = 8; }
         else if( a == "--numa" ) { mode = "numa"; partBytes = 1ull << 30; }
