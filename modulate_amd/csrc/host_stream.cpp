@@ -159,7 +159,7 @@ MODGPU_KNOB_STORAGE uint64_t kFeedChunk = (uint64_t)MODGPU_KNOB("MODGPU_HOST_FEE
 constexpr uint32_t kFeedChunksMax = 8192;      // ready / done words per call (larger calls take larger chunks)
 constexpr uint64_t kFeedBelow = 2ull << 30;    // from here up a launch per 8 MiB chunk is as good or better (4 GiB: 49.3 against 48.7 GB/s, profiles/r05_pcie_feed.txt)
 constexpr uint32_t kFeedGrid = 32;             // workgroups of the host-fed kernel: what saturates the link (profiles/r05_pcie_persist.txt)
-constexpr uint64_t kFeedPatienceTicks = 200000000ull; // 2 s of the 100 MHz wall clock: a chunk the host has not delivered by then never comes
+constexpr uint64_t kFeedPatienceTicks = 1000000000ull; // 10 s of the 100 MHz wall clock: a chunk the host has not delivered by then never comes
 
 // ---- host-side timeline of the staged / pinned routes (modgpu_host_trace, reporting only) --------------------------------
 std::atomic<bool> g_trace_on{false};
@@ -448,9 +448,10 @@ std::vector<Piece> cut_stream(uint64_t n, uint64_t chunk, int pipes, uint64_t ra
 
 constexpr int kStopped = -1000; // run_pipe: another pipeline of the call failed and this one stopped early -- not an error of its own
 
-// Waits until the host-fed kernel has marked chunk c done.  Spins (the wait is tens of microseconds while the call is healthy), and every
-// ~50 us looks at the rest of the world: a sibling pipeline that failed, and the kernel's stream -- a kernel that has ended without
-// finishing the chunk gave up (it waited too long for the host) or died, and either way the chunk will never be done by it.
+// Waits until the host-fed kernel has marked chunk c done.  Spins (the wait is tens of microseconds while the call is healthy); every
+// ~50 us it looks at the call -- a sibling pipeline that failed --, every millisecond at the kernel's stream -- a kernel that has ended
+// without finishing the chunk gave up (it waited too long for the host) or died, and either way the chunk will never be done by it --, and
+// from then on it gives the CPU away between looks (a host with fewer CPUs than pipelines must not burn its quota here).
 int feed_wait(Job &j, uint64_t c)
 {
     uint32_t spins = 0;
@@ -458,9 +459,11 @@ int feed_wait(Job &j, uint64_t c)
         _mm_pause();
         if ((++spins & 1023u) != 0) continue;
         if (j.failed.load(std::memory_order_acquire)) return kStopped;
+        if ((spins & 16383u) != 0) continue;
         const hipError_t q = hipStreamQuery(j.feed_stream);
         if (q == hipErrorNotReady) {
             (void)hipGetLastError();
+            std::this_thread::yield();
             continue;
         }
         if (__atomic_load_n(&j.feed_done[c], __ATOMIC_ACQUIRE) != 0u) break; // (it finished the chunk and then ended)
