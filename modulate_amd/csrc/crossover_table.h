@@ -8,10 +8,10 @@
 
 namespace crossover {
 
-// kernel route, PAGEABLE caller memory (staged: memcpy -> pinned slot -> kernel across PCIe -> memcpy back)
+// kernel route, PAGEABLE caller memory (staged: copy -> pinned slot -> kernel across PCIe on the slot -> copy back)
 struct Point { uint64_t bytes; double gbps; };
-constexpr Point kKernelPageable[] = { // round 5 (32 workgroups per short launch across the link, ~64 chunks of >= 1 MiB): profiles/r05_small_call_crossover.txt
-    {4ull << 20, 22.4}, {8ull << 20, 32.4}, {16ull << 20, 35.4}, {32ull << 20, 39.1}, {64ull << 20, 40.7}, {128ull << 20, 43.5}, {256ull << 20, 45.6}, {1024ull << 20, 47.2}, {4096ull << 20, 48.0},
+constexpr Point kKernelPageable[] = { // end of round 5 (one host-fed kernel per call below 2 GiB, a launch per 8 MiB chunk above): profiles/r05_small_call_crossover.txt
+    {4ull << 20, 29.2}, {8ull << 20, 36.7}, {16ull << 20, 41.5}, {32ull << 20, 45.0}, {64ull << 20, 46.9}, {128ull << 20, 47.8}, {256ull << 20, 48.4}, {1024ull << 20, 48.6}, {4096ull << 20, 49.3},
 };
 // kernel route, PAGE-LOCKED caller memory (modgpu_host_alloc / _register): one kernel across PCIe where the pages lie
 constexpr double kKernelPinnedGbps = 50.0;     // profiles/r02_sweep_pinned_routes.txt

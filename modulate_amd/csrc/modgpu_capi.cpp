@@ -60,7 +60,7 @@ int fail_io(const char *what)
 // largest header the reference can write, CArk.cpp:911-912) 30 us against 44 (profiles/r05_small_call_crossover.txt).  Since
 // round 5's short-launch grid and finer cut the kernel route overtakes ONE host thread at 2 MiB already (it was 16-32 MiB when
 // this default was chosen, r03), but from 4 MiB the host loop runs on several threads and stays ahead up to this size
-// (4 / 8 / 16 MiB: 31 / 60 / 117 GB/s against 22 / 32 / 35), so below it a call is over sooner on the host whichever way one
+// (4 / 8 / 16 MiB: 31 / 61 / 115 GB/s against 29 / 37 / 42), so below it a call is over sooner on the host whichever way one
 // counts; from here up the default policy (below) gives the buffer to the GPU and the cores back to the caller.
 constexpr uint64_t kMinGpuBytesDefault = 16ull << 20;
 uint64_t min_gpu_bytes()

@@ -71,5 +71,5 @@ bench)        # profiles/r05_bench.json, r05_pmc_summary.json (+ profiles/pmc_su
     python3 tools/bench_configs.py --out $O/r05_configs.json ;;
 crossover)    # profiles/r05_small_call_crossover.txt: both engines per call (the table MODGPU_HOST_POLICY=fastest decides by)
     modulate_amd/bin/modbench --hostcall > $O/r05_hostcall.txt ;;
-*) echo "usage: tools/reproduce_r05.sh build | pcie [tag] | grid | wake | lsp | lspcounters | config5 | soak | numa | bench | crossover" ;;
+*) echo "usage: tools/reproduce_r05.sh build | pcie [tag] | feed | grid | wake | lsp | lspcounters | config5 | soak | numa | bench | crossover" ;;
 esac
