@@ -12,10 +12,14 @@
 //                     one side of a file stream is pinned memory, that side is DMA'd directly or -- file ->
 //                     page-locked memory -- read into the destination itself and cycled where it lies.
 //   pageable, large   copy -> pinned slot -> kernel across PCIe on the slot -> copy back, spread over kPipes
-//                     independent pipelines (host thread + two slots each, double-buffered), the stream cut into
-//                     ~64 pieces of >= 1 MiB behind a 512 KiB ramp, the kernels queued on 4 shared lanes:
-//                     36.5 / 43.6 / 46.4 / 48.1 GB/s at 16 / 64 / 256 / 1024 MiB.  (Testing flavour, staged mode 1:
-//                     copy -> H2D DMA -> kernel in HBM -> D2H DMA -> copy, round 1's form, 27-30 GB/s.)
+//                     independent pipelines (host thread + two slots each, double-buffered).  Below 2 GiB the kernel is ONE
+//                     host-fed launch per call (cycle_feed_kernel.h): 256 KiB chunks, a pipeline marks its chunk ready in
+//                     page-locked memory and polls the chunk's done word -- 39.8 / 46.1 / 47.7 / 48.4 GB/s at 16 / 64 /
+//                     256 / 1024 MiB (profiles/r05f_pcie_route_staged_*).  From 2 GiB up, and with a file on either side, a
+//                     launch per chunk: ~64 pieces of >= 1 MiB (<= 8 MiB) behind a 512 KiB ramp, the kernels queued on 4
+//                     shared lanes (36.5 / 43.6 / 46.4 / 48.1 on the sizes above, profiles/r05_pcie_route_staged_*).
+//                     (Testing flavour, staged mode 1: copy -> H2D DMA -> kernel in HBM -> D2H DMA -> copy, round 1's form,
+//                     27-30 GB/s; mode 2: the launch per chunk everywhere.)
 //                     A file endpoint replaces its copy by pread / pwrite on the pinned slot.
 //   small (<= 1 MiB)  what the reference's three call sites pass (headers): one slot, one kernel across PCIe,
 //                     no DMA submissions, no workers.
