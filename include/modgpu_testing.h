@@ -147,7 +147,8 @@ enum { MODGPU_TUNABLE_ZEROCOPY_BYTES = 0, MODGPU_TUNABLE_RING = 1, MODGPU_TUNABL
        MODGPU_TUNABLE_RAMP_BYTES = 4, MODGPU_TUNABLE_LANES = 5, MODGPU_TUNABLE_NTCOPY = 6,
        MODGPU_TUNABLE_FILE_SCHED = 7, /* 1 (the shipped rule): file -> memory is cut and queued like a memory-to-memory call; 0: like the other file routes */
        MODGPU_TUNABLE_FEED = 8,       /* 1 (the shipped rule): pageable memory on both sides is cycled by ONE host-fed kernel per call; 0: a launch per chunk */
-       MODGPU_TUNABLE_FEED_CHUNK_BYTES = 9 /* chunk of a host-fed call (256 KiB; whole 32 KiB pieces) */ };
+       MODGPU_TUNABLE_FEED_CHUNK_BYTES = 9, /* chunk of a host-fed call (256 KiB; whole 32 KiB pieces) */
+       MODGPU_TUNABLE_FEED_PATIENCE_MS = 10 /* how long the host-fed kernel waits for one chunk before it gives the call up (10 000) */ };
 void modgpu_debug_set_host_tunable(int which, uint64_t value);
 
 /* The NUMA node the library believes its GPUs hang off (-1 = unknown, -2 = ask sysfs, the default).  Lets a one-node machine
@@ -180,8 +181,11 @@ void modgpu_debug_inject_failures(int count);
  * MODGPU_INJECT_PIECE_LAST / _MIDDLE name the last piece and the one at half the plan, and an index beyond the plan means the last.
  * Stages: FILL = before the piece is copied / read into its slot; LAUNCH = filled, the kernel launch fails; SYNC = the wait for
  * the piece's kernel fails (what a GPU dying under way looks like); DRAIN = the kernel finished, the failure comes before the
- * piece is copied back; AFTER_DRAIN = the piece HAS been copied back, then the failure.  stage < 0 disarms. */
-enum { MODGPU_STAGE_FILL = 0, MODGPU_STAGE_LAUNCH = 1, MODGPU_STAGE_SYNC = 2, MODGPU_STAGE_DRAIN = 3, MODGPU_STAGE_AFTER_DRAIN = 4 };
+ * piece is copied back; AFTER_DRAIN = the piece HAS been copied back, then the failure.  stage < 0 disarms.
+ * STALL is not a failure of a HIP call but of the HOST: the pipeline thread sleeps for four times the host-fed kernel's patience
+ * (MODGPU_TUNABLE_FEED_PATIENCE_MS) before it copies the piece in -- the kernel must give the call up by itself, and the call must
+ * end like any other that lost its GPU under way (only calls that take the host-fed kernel have this stage). */
+enum { MODGPU_STAGE_FILL = 0, MODGPU_STAGE_LAUNCH = 1, MODGPU_STAGE_SYNC = 2, MODGPU_STAGE_DRAIN = 3, MODGPU_STAGE_AFTER_DRAIN = 4, MODGPU_STAGE_STALL = 5 };
 #define MODGPU_INJECT_PIECE_LAST (-1)
 #define MODGPU_INJECT_PIECE_MIDDLE (-2)
 void modgpu_debug_inject_failure_at(int64_t piece, int stage);

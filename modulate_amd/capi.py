@@ -267,7 +267,7 @@ def debug_set_staged_mode(mode=0):
 
 
 HOST_TUNABLES = {"zerocopy_bytes": 0, "ring": 1, "split": 2, "chunk_min_bytes": 3, "ramp_bytes": 4, "lanes": 5, "ntcopy": 6, "file_sched": 7,
-                 "feed": 8, "feed_chunk_bytes": 9}
+                 "feed": 8, "feed_chunk_bytes": 9, "feed_patience_ms": 10}
 
 
 def debug_set_host_tunable(name, value):
@@ -290,7 +290,7 @@ def debug_inject_failures(count):
     _debug_lib().modgpu_debug_inject_failures(count)
 
 
-STAGE_FILL, STAGE_LAUNCH, STAGE_SYNC, STAGE_DRAIN, STAGE_AFTER_DRAIN = range(5)
+STAGE_FILL, STAGE_LAUNCH, STAGE_SYNC, STAGE_DRAIN, STAGE_AFTER_DRAIN, STAGE_STALL = range(6)
 INJECT_PIECE_LAST, INJECT_PIECE_MIDDLE = -1, -2
 
 

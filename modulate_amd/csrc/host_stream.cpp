@@ -48,6 +48,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -163,7 +164,7 @@ MODGPU_KNOB_STORAGE uint64_t kFeedChunk = (uint64_t)MODGPU_KNOB("MODGPU_HOST_FEE
 constexpr uint32_t kFeedChunksMax = 8192;      // ready / done words per call (larger calls take larger chunks)
 constexpr uint64_t kFeedBelow = 2ull << 30;    // from here up a launch per 8 MiB chunk is as good or better (4 GiB: 49.3 against 48.7 GB/s, profiles/r05_pcie_feed.txt)
 constexpr uint32_t kFeedGrid = 32;             // workgroups of the host-fed kernel: what saturates the link (profiles/r05_pcie_persist.txt)
-constexpr uint64_t kFeedPatienceTicks = 1000000000ull; // 10 s of the 100 MHz wall clock: a chunk the host has not delivered by then never comes
+MODGPU_KNOB_STORAGE uint64_t kFeedPatienceTicks = 1000000000ull; // 10 s of the 100 MHz wall clock: a chunk the host has not delivered by then never comes
 
 // ---- host-side timeline of the staged / pinned routes (modgpu_host_trace, reporting only) --------------------------------
 std::atomic<bool> g_trace_on{false};
@@ -564,6 +565,10 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
                 return rc;
             }
             if (j.slot_kernel) { // neither side is pinned caller memory: the slot itself is the device-visible copy
+                if (j.feed && injected_at(c, n_chunks, MODGPU_STAGE_STALL)) { // (testing flavour) the host goes away for a while: the kernel has to give up by itself
+                    trace(MODGPU_TRACE_FAILED, pipe, c, (uint64_t)MODGPU_STAGE_STALL);
+                    std::this_thread::sleep_for(std::chrono::microseconds(4 * kFeedPatienceTicks / 100));
+                }
                 int rc = fill_slot(j.src, s.pinned[slot], off, len);
                 if (rc) return rc;
                 trace(MODGPU_TRACE_FILL_END, pipe, c, len);
@@ -1045,7 +1050,7 @@ void modgpu_debug_inject_failure_at(int64_t piece, int stage)
 {
     g_inject_stage.store(-1, std::memory_order_release);
     g_inject_piece.store(piece, std::memory_order_relaxed);
-    g_inject_stage.store(stage >= MODGPU_STAGE_FILL && stage <= MODGPU_STAGE_AFTER_DRAIN ? stage : -1, std::memory_order_release);
+    g_inject_stage.store(stage >= MODGPU_STAGE_FILL && stage <= MODGPU_STAGE_STALL ? stage : -1, std::memory_order_release);
 }
 int modgpu_debug_injection_armed(void) { return g_inject_stage.load(std::memory_order_acquire) >= 0 ? 1 : 0; }
 // Takes `count` PIPELINE slots of a device's own staging set, as large calls do, and keeps them until called with count = 0: with all
@@ -1077,6 +1082,7 @@ void modgpu_debug_set_host_tunable(int which, uint64_t value)
     case MODGPU_TUNABLE_FILE_SCHED: kFileSched = value != 0; break;
     case MODGPU_TUNABLE_FEED: kFeed = value != 0; break;
     case MODGPU_TUNABLE_FEED_CHUNK_BYTES: kFeedChunk = clamp(value, 32ull << 10, 8ull << 20); break;
+    case MODGPU_TUNABLE_FEED_PATIENCE_MS: kFeedPatienceTicks = clamp(value, 1, 600000) * 100000ull; break;
     default: break;
     }
 }

@@ -91,6 +91,39 @@ for n in sizes:
     cycle(buf)
     assert np.array_equal(buf, want) and M.path_stats()["midcall_rescues"] == before["midcall_rescues"]
 
+# ---- not the GPU but the HOST goes away: a pipeline thread stalls for four times the host-fed kernel's patience before it copies its piece
+# in.  The kernel must give the call up by itself (every workgroup that waits for that chunk leaves, the others run out of tickets), the
+# pipeline finds the kernel gone and the chunk undone, and the call ends like any other that lost its GPU under way.
+import time  # noqa: E402
+n = sizes[0]
+pt = np.resize(O.splitmix_bytes(min(n, 64 << 20), 10), n)
+want = pt.copy()
+O.cycle_at(want, O.KEY_PS4, 0)
+M.debug_set_host_tunable("feed_patience_ms", 40)
+try:
+    buf = pt.copy()
+    before = M.path_stats()
+    M.debug_inject_failure_at(M.INJECT_PIECE_MIDDLE, M.STAGE_STALL)
+    t0 = time.perf_counter()
+    try:
+        cycle(buf)
+        assert not strict, "MODGPU_REQUIRE_GPU=1 must not compute on the host"
+    except Exception as e:  # noqa: BLE001
+        assert strict and "gave up" in str(e), str(e)
+    waited = time.perf_counter() - t0
+    assert not M.debug_injection_armed() and 0.15 < waited < 20.0, waited
+    if not strict:
+        after = M.path_stats()
+        assert np.array_equal(buf, want) and after["midcall_rescues"] == before["midcall_rescues"] + 1, (before, after)
+    buf = pt.copy()  # and the next call finds a clean slate: no kernel left behind, counters at zero
+    if strict:
+        M.cycle_host(buf, M.KEY_PS4)
+    else:
+        cycle(buf)
+    assert np.array_equal(buf, want) and M.last_launch()["variant"] == 4
+finally:
+    M.debug_set_host_tunable("feed_patience_ms", 10000)
+
 if not strict:
     n = sizes[0]
     pt = np.resize(O.splitmix_bytes(min(n, 64 << 20), 9), n)

@@ -461,7 +461,9 @@ def test_gpu_lost_in_the_middle_of_a_call(gpu, case):
     testing flavour by preloading it), which must return normally.  `strict`: with MODGPU_REQUIRE_GPU=1 nothing computes on the
     host and the error comes back.  Also in the child: page-locked memory in place (launch failure -> whole buffer on the host
     loop; kernel dies under way -> the one documented error), header-sized buffers, modgpu_cycle_file_to_host on pageable and
-    page-locked destinations (tests/_midcall_child.py)."""
+    page-locked destinations (tests/_midcall_child.py).
+    Last case of the child: not the GPU but the HOST goes away -- a pipeline thread stalls for four times the host-fed kernel's (shortened)
+    patience; the kernel gives the call up by itself and the call ends like the others (rescued, or the error when the host loop is forbidden)."""
     env = dict(os.environ, MODGPU_REQUIRE_GPU="1" if case.startswith("strict") else "0", MODGPU_MIN_GPU_BYTES="65536")
     args = [sys.executable, os.path.join(ROOT, "tests", "_midcall_child.py"), "64,1024" if case.startswith("auto") else "64", "--files", "/dev/shm"]
     if case.startswith("class"):
