@@ -7,9 +7,14 @@ A "step" is one encrypt pass + one decrypt pass of the cipher hot path
 (modgpu_cycle_device).  With N GPUs every rank owns one such part (parts are independent
 streams: no collective on the data path, weak scaling).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+The first form needs no launcher: with N > 1 and no WORLD_SIZE in the environment this process never touches the GPU -- it
+starts N fresh rank processes (one per GPU), relays rank 0's line and exits with the worst of their statuses.  Either way the
+ranks meet for the contract's barrier and MAX over a loopback socket (modulate_amd/rendezvous.py): no torch, no RCCL -- the
+workload has no exchange step.  `--backend gloo|nccl` puts torch.distributed there instead.
 
 Rank 0 prints ONE JSON line.  `value` = part bytes cycled per second summed over all ranks
 (each pass over a byte counts once; HBM traffic is twice that: 1 read + 1 write per byte).
@@ -17,7 +22,10 @@ Rank 0 prints ONE JSON line.  `value` = part bytes cycled per second summed over
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -27,7 +35,7 @@ sys.path.insert(0, ROOT)
 # Read once when libmodgpu.so is loaded: forbids the library's host loop, so that nothing this script
 # times or checks can have been computed anywhere but on the GPU (the run fails instead).
 os.environ["MODGPU_REQUIRE_GPU"] = "1"
-# multi-rank runs: the host driver of this pool supports dmabuf IPC only (RCCL's barrier shares device memory across ranks)
+# --backend nccl only: the host driver of this pool supports dmabuf IPC only (RCCL's barrier shares device memory across ranks)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
@@ -146,6 +154,54 @@ class _StdoutToStderr:
         return False
 
 
+def launch_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` by itself: start N NEW processes of this script, rank r on GPU r, and wait for them.
+    This process stays off the GPU (it never imports modulate_amd); no process that has opened the GPU is replaced or
+    re-executed; a failing rank is a non-zero exit, upon which the others are ended by PID.  Rank 0's stdout is relayed as the
+    last thing on this process's stdout; the other ranks' stdout goes to stderr.  Returns the worst child status."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MODGPU_BENCH_RDZV=f"tcp:127.0.0.1:{port}", MODGPU_BENCH_LAUNCHER="bench.py")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    rank0_out = []
+    reader = threading.Thread(target=lambda: rank0_out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    worst = 0
+    live = set(range(n_ranks))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            rc = 128 - rc if rc < 0 else rc  # ended by a signal
+            if rc != 0:
+                print(f"bench.py: rank {r} exited with status {rc}", file=sys.stderr)
+                worst = max(worst, rc)
+        if worst and live:  # one rank failed: the others would wait for it at the next barrier
+            for r in live:
+                procs[r].terminate()
+            deadline = time.monotonic() + 10.0
+            for r in live:
+                try:
+                    procs[r].wait(timeout=max(0.1, deadline - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+                    procs[r].wait()
+            live.clear()
+        time.sleep(0.05)
+    reader.join(timeout=10.0)
+    sys.stdout.write("".join(rank0_out))
+    sys.stdout.flush()
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,32 +212,44 @@ def main():
     ap.add_argument("--cpu-sample-bytes", type=int, default=3 << 29, help="bytes of the bounded CPU-baseline sample (default 1.5 GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-first-pass", action="store_true", help="skip the first-pass preamble (14 launches before the warm-up)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier/MAX (nccl = RCCL); "
-                    "gloo is for rehearsing N>1 on a box with fewer GPUs")
+    ap.add_argument("--backend", default="socket", choices=("socket", "gloo", "nccl"),
+                    help="control plane for the barrier / MAX over ranks: socket = a loopback rendezvous, no torch (default); "
+                         "gloo = torch.distributed on CPU tensors; nccl = RCCL on device tensors")
     ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: every rank uses this HIP device")
-    ap.add_argument("--force-dist", action="store_true", help="rehearsal only: initialise the process group even with one rank")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal only: bring the control plane up even with one rank")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
     if a.force_dist:
         os.environ["MODGPU_BENCH_FORCE_DIST"] = "1"
+    use_control_plane = int(os.environ.get("WORLD_SIZE", "1")) > 1 or a.force_dist
+    use_torch = use_control_plane and a.backend != "socket"
 
     # One HIP runtime per process: PyTorch bundles its own libamdhip64.so, libmodgpu.so binds to the
-    # same SONAME.  Whichever is loaded first serves both, so with several ranks torch (RCCL barrier)
-    # is imported BEFORE the product library is first used; with one rank torch is never imported.
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or a.force_dist:
+    # same SONAME.  Whichever is loaded first serves both, so when torch.distributed is the control plane torch
+    # is imported BEFORE the product library is first used; otherwise torch is never imported.
+    if use_torch:
         import torch  # noqa: F401
     import modulate_amd as M
     from modulate_amd import sharding
 
     rank, local_rank, world = sharding.dist_env()
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-        a.gpus = world
+    a.gpus = world
     dist = None
+    plane = None
     red_dev = None
-    if world > 1 or a.force_dist:
+    launcher = os.environ.get("MODGPU_BENCH_LAUNCHER") or ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "none")
+    control_plane = "none (one rank)"
+    if use_control_plane and not use_torch:
+        from modulate_amd import rendezvous
+        plane = rendezvous.LoopbackPlane(rank, world)
+        sharding.use_plane(plane)
+        plane.barrier()
+        control_plane = f"socket: loopback rendezvous ({plane.address.split(':')[0]}), standard library only -- no torch, no RCCL"
+    elif use_torch:
         import torch
         import torch.distributed as dist
+        control_plane = "nccl: torch.distributed over RCCL, device tensors" if a.backend == "nccl" else "gloo: torch.distributed, CPU tensors"
         with _StdoutToStderr():
             if a.backend == "nccl":
                 # one rank per GPU; if the launcher already narrowed each rank's visibility to one device
@@ -208,9 +276,8 @@ def main():
 
     def barrier():
         part.sync()
-        if dist is not None:
-            dist.barrier()
-            part.sync()
+        sharding.barrier_over_ranks()
+        part.sync()
 
     # ---- the first-pass regime (outside the timed region; reported beside the steady-state figure).
     # A real job makes ONE pass per part right after something else wrote it (BASELINE configs 3-5); the timed region
@@ -314,6 +381,7 @@ def main():
                                    f"{'s, one per GPU' if world > 1 else ''}, encrypt pass + decrypt pass per step, "
                                    f"HBM-resident, key {a.key:#010x}",
                        "part_bytes": n, "passes_per_step": 2, "parallelism": f"parts{world}",
+                       "control_plane": control_plane, "launcher": launcher,
                        "value_counts": "payload bytes cycled per second (HBM read+write traffic is 2x)",
                        "bit_exact_check": ("pass" if n_ok == world else "FAIL") + f" (involution + {checked} golden keystream samples per rank)",
                        "engine": f"gfx950 kernel only (MODGPU_REQUIRE_GPU=1): {stats['gpu_launches']} launches, "
@@ -332,6 +400,9 @@ def main():
             out["roofline"]["first_pass"] = first_pass
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample_bytes)
+    if plane is not None:
+        plane.barrier()
+        plane.close()
     if dist is not None:
         with _StdoutToStderr():  # (nothing of the teardown may reach stdout either)
             dist.barrier()

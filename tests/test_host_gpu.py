@@ -422,6 +422,31 @@ def test_config5_full_scale_eight_workers_one_worker_and_the_cpu_path(host, orac
     b.close()
 
 
+def test_bench_gpus_two_by_itself(host):
+    """`python3 bench.py --gpus N --steps K --warmup W` produces the N-GPU line BY ITSELF -- no launcher, no torch,
+    no RCCL.  The parent never opens the GPU; it starts two fresh rank processes that meet on a loopback socket for the
+    contract's barrier and MAX (the parts are independent streams, Modulate/CArk.cpp:741-755, 849-897: no exchange step).  Both
+    ranks on the box's one GPU here (`--force-device 0`); this runner + two ranks hold the card: within the guard's six."""
+    import json
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MODGPU_BENCH_RDZV", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--force-device", "0", "--steps", "3", "--warmup", "1",
+                        "--part-bytes", "335544320"], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    printed = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(printed) == 1, r.stdout  # ONE line, and it is the last (only) thing on stdout
+    out = json.loads(printed[-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3 and out["warmup"] == 1
+    assert "config 3: 2 x 335544320 B" in out["config"]["workload"] and out["config"]["bit_exact_check"].startswith("pass (")
+    assert out["config"]["control_plane"].startswith("socket") and out["config"]["launcher"] == "bench.py"
+    assert "cpu_baseline" not in out
+    assert abs(out["value"] - 2 * 3 * 2 * 335544320 / (out["ms_per_step"] * 3 * 1e-3) / 1e9) / out["value"] < 0.01
+    # no torch anywhere in it: neither imported by a rank (its import would print nothing, so ask the ranks' own report) nor needed
+    assert "no torch" in out["config"]["control_plane"] and "RCCL version" not in (r.stdout + r.stderr)
+
+
 def test_bench_two_ranks_rehearsal(host, tmp_path):
     """The driver's N>1 launch line (torch.distributed.run, one rank per GPU) rehearsed with 2 ranks on this
     box's one GPU: gloo for the barrier / MAX (RCCL wants one GPU per rank), both ranks on device 0.
@@ -449,6 +474,7 @@ def test_bench_two_ranks_rehearsal(host, tmp_path):
     assert "config 3" in out["config"]["workload"] and out["config"]["bit_exact_check"].startswith("pass")
     assert out["roofline"]["kernel"].startswith("modgpu_cycle_queue_kernel<4, 1024>") and out["roofline"]["main_workgroups"] == 200 and out["roofline"]["grid"] == 256
     assert "cpu_baseline" not in out  # rank 0 at N=1 only
+    assert out["config"]["control_plane"].startswith("gloo") and out["config"]["launcher"] == "torch.distributed.run"
     assert abs(out["value"] - 2 * 3 * 2 * (320 << 20) / (out["ms_per_step"] * 3 * 1e-3) / 1e9) / out["value"] < 0.01
 
 
@@ -458,8 +484,9 @@ def test_bench_driver_launch_line_four_ranks_full_size_parts(host):
     the guard: "8 processes had the GPU open (limit 6)") -- and the operating rules forbid starting the N = 8 case ourselves.  So
     this runs the driver's line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N --steps 20 --warmup 5`, its flags and counts unchanged -- with N = 4, the largest of the
-    driver's own N = 1, 2, 4, 8 that fits, at the DEFAULT part size (4 x 4 GiB resident), all ranks on device 0 (`--backend gloo
-    --force-device 0`: RCCL wants a GPU per rank).  One JSON line, last on stdout; whole-job value over four ranks; bit-exact on
+    driver's own N = 1, 2, 4, 8 that fits, at the DEFAULT part size (4 x 4 GiB resident), all ranks on device 0 (`--force-device 0`)
+    and the DEFAULT control plane: under torch.distributed.run too the ranks meet on the loopback socket (an abstract Unix
+    socket named after MASTER_PORT, which the launcher's own store occupies), not on a torch process group.  One JSON line, last on stdout; whole-job value over four ranks; bit-exact on
     every rank.  Four ranks on one GPU take turns, so the aggregate must come out near the one-rank figure -- which is all this
     can say about scaling: nothing."""
     import json
@@ -493,7 +520,7 @@ def test_bench_driver_launch_line_four_ranks_full_size_parts(host):
     n = max(2, 4 - others_holding_the_gpu())  # this runner + the launcher + n ranks must stay within the guard's six
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "20", "--warmup", "5",
-                        "--backend", "gloo", "--force-device", "0"],
+                        "--force-device", "0"],
                        capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -504,6 +531,7 @@ def test_bench_driver_launch_line_four_ranks_full_size_parts(host):
     assert out["config"]["part_bytes"] == 1 << 32 and f"config 3: {n} x 4294967296 B" in out["config"]["workload"]
     assert out["config"]["bit_exact_check"].startswith("pass") and out["config"]["parallelism"] == f"parts{n}"
     assert out["metric"] == one_rank["metric"] and "cpu_baseline" not in out
+    assert out["config"]["control_plane"].startswith("socket: loopback rendezvous (unix)") and out["config"]["launcher"] == "torch.distributed.run"
     assert abs(out["value"] - n * 20 * 2 * (1 << 32) / (out["ms_per_step"] * 20 * 1e-3) / 1e9) / out["value"] < 0.01
     # four ranks share one GPU: whole-job throughput ~ the one-rank figure (their launches take turns; nothing is gained or lost)
     assert 0.85 * one_rank["value"] <= out["value"] <= 1.10 * one_rank["value"], (one_rank["value"], out["value"])
@@ -521,7 +549,7 @@ def test_bench_nccl_branch_single_rank(host):
     s.close()
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                        "--part-bytes", str(320 << 20), "--force-dist", "--no-cpu-baseline"],
+                        "--part-bytes", str(320 << 20), "--force-dist", "--backend", "nccl", "--no-cpu-baseline"],
                        capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     # the contract: ONE JSON line on stdout and nothing else -- RCCL's version banner (printed from C when the communicator
