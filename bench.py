@@ -212,6 +212,8 @@ def main():
     ap.add_argument("--cpu-sample-bytes", type=int, default=3 << 29, help="bytes of the bounded CPU-baseline sample (default 1.5 GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-first-pass", action="store_true", help="skip the first-pass preamble (14 launches before the warm-up)")
+    ap.add_argument("--no-own-upload-probe", action="store_true", help="skip the fresh child process that uploads with its own hipMemcpy and calls "
+                    "modgpu_prepare (first_pass.callers_own_upload_after_modgpu_prepare; N = 1 only; tools/profile.sh skips it)")
     ap.add_argument("--backend", default="socket", choices=("socket", "gloo", "nccl"),
                     help="control plane for the barrier / MAX over ranks: socket = a loopback rendezvous, no torch (default); "
                          "gloo = torch.distributed on CPU tensors; nccl = RCCL on device tensors")
@@ -266,6 +268,18 @@ def main():
         raise SystemExit("no HIP device: bench.py measures the HIP path only")
     dev = local_rank if a.force_device is None else a.force_device
 
+    # A caller that brings its OWN device memory (hipMalloc / hipMemcpy of its own) gets the library's device preparation and wake-up
+    # by name: modgpu_prepare (ABI 8).  Measured in a fresh child process -- a process's first launch is the point -- before this
+    # process has queued anything, N = 1 only: tools/first_launch_own_upload.py.  Outside every timed region; reporting only.
+    own_upload = None
+    if world == 1 and not a.no_first_pass and not a.no_own_upload_probe and a.force_device in (None, 0):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_launch_own_upload.py"), "--prepare", "--bytes", str(min(a.part_bytes, 411 * 1000 * 1000))],
+                               capture_output=True, text=True, timeout=120, cwd=ROOT)
+            own_upload = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-200:]}
+        except Exception as e:  # informational: never fails the bench
+            own_upload = {"error": str(e)[:200]}
+
     n = a.part_bytes
     # synthetic part: uniform random bytes (values do not affect timing; they make the checks real)
     rng = np.random.default_rng(0x4D6F6475 + rank)
@@ -307,6 +321,11 @@ def main():
                       # first wave (the host's planning and packet write, the chip bringing its shader engines up) -- the dispatch itself
                       # takes 0.127-0.128 ms here by rocprofv3's timestamps, 0.80-0.81 of peak (profiles/r05_first_launch.txt, run F)
                       "part_411MB": rate(small_n, t_small), "part_411MB_next_launch": rate(small_n, t_small_again),
+                      # the same first launch for the two kinds of caller (include/modgpu.h, device-memory helpers): one that uploads through
+                      # modgpu_alloc / modgpu_h2d (this process: == part_411MB), and one with its own hipMalloc / hipMemcpy that calls
+                      # modgpu_prepare when its upload starts (a fresh child process, tools/first_launch_own_upload.py)
+                      "via_library_upload": rate(small_n, t_small),
+                      "callers_own_upload_after_modgpu_prepare": own_upload,
                       "part_411MB_note": "events from an idle queue include dispatch latency; the dispatch itself: 0.127-0.128 ms = 0.80-0.81 (profiles/r05_first_launch.txt run F)",
                       "ms_of_launches_1_to_12": [round(x, 4) for x in series],
                       "slowest_of_launches_1_to_12": rate(n, max(series)),

@@ -93,7 +93,7 @@ extern "C" {
 #define MODGPU_KEY_PS4 0x90cfc0abu
 
 /* ABI version of this header (bumped on any signature change). */
-#define MODGPU_ABI_VERSION 7
+#define MODGPU_ABI_VERSION 8
 int modgpu_abi_version(void);
 
 /* Number of HIP devices this library addresses (0 if none / runtime unusable).  Normally the
@@ -295,12 +295,29 @@ int modgpu_host_policy_engine(uint64_t n, int pinned, double *host_us, double *k
 /* The host-loop body this process uses: "generic", "avx2" or "avx512".  Static storage. */
 const char *modgpu_host_loop_isa(void);
 
-/* ---- thin device-memory helpers (bench / tests / callers that keep parts resident) --- */
+/* ---- device-memory helpers (bench / tests / callers that keep parts resident) ---------
+ * hipMalloc / hipFree / hipMemcpy / a synchronize on the named device -- plus two pieces of housekeeping that are NOT in their
+ * names, both best effort (whatever fails there is retried or simply paid by the caller's first launch) and both outside
+ * anybody's timed launch:
+ *   modgpu_alloc   the FIRST allocation on a device in this process also prepares the device: the code object is loaded, the
+ *                  work-queue kernel's ticket ring is set up, and two real, tiny work-queue launches (2 x 64 KiB of scratch) run
+ *                  and are waited for on a private stream.  A process's first real launch of that kernel otherwise costs 10 ms
+ *                  (code object) + 15-35 us (kernel function, ring) inside whatever the caller times
+ *                  (profiles/r03_first_pass.txt, r05_first_launch.txt).
+ *   modgpu_h2d     a copy of 1 MiB or more first enqueues ONE EMPTY KERNEL (one workgroup, no words) on a private non-blocking
+ *                  stream that nobody waits for: an upload keeps only the DMA engines busy, the shader engines fall asleep within a
+ *                  fraction of a second, and the first launch behind the upload would pay their wake-up (~15 us on a 411 MB part:
+ *                  0.72 -> 0.81 of the HBM peak for that launch).  Costs the caller one asynchronous launch call per copy.
+ * A caller that brings its own device memory (hipMalloc / hipMemcpy of its own, a torch tensor) gets neither -- unless it says so:
+ *   modgpu_prepare(device)   both of the above by name: prepares the device if this process has not yet, and enqueues the empty
+ *                  wake-up launch.  Call it when your own upload STARTS (or any time before the first modgpu_cycle_device).
+ *                  Never required for correctness.  Returns MODGPU_OK, or the error of selecting the device. */
 int modgpu_alloc(void **dev_ptr, uint64_t n, int device);
 int modgpu_free(void *dev_ptr, int device);
 int modgpu_h2d(void *dev_dst, const void *host_src, uint64_t n, int device);
 int modgpu_d2h(void *host_dst, const void *dev_src, uint64_t n, int device);
 int modgpu_sync(int device, void *hip_stream);
+int modgpu_prepare(int device);
 
 /* ---- host-side jump-ahead arithmetic (exposed so it can be checked without a GPU) ---- */
 

@@ -33,13 +33,16 @@ typedef struct modgpu_launch_info {
     const char *kernel;   /* the instantiation's name as rocprofv3 prints it, e.g.
                              "modgpu_cycle_queue_kernel<4, 1024>"; static storage */
     int variant;          /* 0 = small shape, 1 = streaming shape (static chunk map), 2 = streaming shape fed by the work queue,
-                             3 = the work-queue shape over several parts in one launch (modgpu_cycle_batch_device; `bytes` = all of them) */
+                             3 = the work-queue shape over several parts in one launch (modgpu_cycle_batch_device; `bytes` = all of them),
+                             4 = the host-fed kernel of a host-buffer call (one launch for the whole call; `bytes` = the call's) */
     uint32_t grid;        /* workgroups launched                                                  */
     uint32_t block;       /* threads per workgroup                                                */
     uint32_t chunk_bytes; /* bytes one workgroup trip covers                                      */
     uint64_t bytes;       /* n of that launch                                                     */
     uint32_t main_groups; /* of `grid`: workgroups that stream from the start; the other grid - main_groups are helper
                              workgroups of the work-queue shape, which join only while the shader clock is low */
+    const char *source_hash; /* identity of the TU that kernel was compiled from: modgpu_kernel_source_hash() for variants 0..3,
+                                modgpu_feed_kernel_source_hash() for variant 4; static storage */
 } modgpu_launch_info_t;
 int modgpu_last_launch(modgpu_launch_info_t *out);
 
@@ -115,6 +118,9 @@ void modgpu_queue_stats(uint64_t out[6]);
  * built from (cycle_kernel_impl.h, cycle_kernel.hip, cycle_kernel.h, lcg.h), fixed at build time.
  * profiles/pmc_summary.json records it so that counter figures are never replayed for other code. */
 const char *modgpu_kernel_source_hash(void);
+/* The same for the host-fed kernel's TU (cycle_feed_kernel.hip, cycle_feed_kernel.h, cycle_kernel_impl.h, lcg.h): every
+ * `roofline_pcie` profile of a host-buffer route records it. */
+const char *modgpu_feed_kernel_source_hash(void);
 
 /* 1 in libmodgpu_testing.so, 0 in libmodgpu.so. */
 int modgpu_testing_hooks(void);
@@ -148,7 +154,9 @@ enum { MODGPU_TUNABLE_ZEROCOPY_BYTES = 0, MODGPU_TUNABLE_RING = 1, MODGPU_TUNABL
        MODGPU_TUNABLE_FILE_SCHED = 7, /* 1 (the shipped rule): file -> memory is cut and queued like a memory-to-memory call; 0: like the other file routes */
        MODGPU_TUNABLE_FEED = 8,       /* 1 (the shipped rule): pageable memory on both sides is cycled by ONE host-fed kernel per call; 0: a launch per chunk */
        MODGPU_TUNABLE_FEED_CHUNK_BYTES = 9, /* chunk of a host-fed call (256 KiB; whole 32 KiB pieces) */
-       MODGPU_TUNABLE_FEED_PATIENCE_MS = 10 /* how long the host-fed kernel waits for one chunk before it gives the call up (10 000) */ };
+       MODGPU_TUNABLE_FEED_PATIENCE_MS = 10, /* how long the host-fed kernel waits for one chunk before it gives the call up (10 000) */
+       MODGPU_TUNABLE_FILE_FEED = 11 /* 1 (the shipped rule): a FILE that ends in memory takes the host-fed kernel too -- through the slots into
+                                        pageable memory, in place into page-locked memory; 0: round 5's launch per chunk */ };
 void modgpu_debug_set_host_tunable(int which, uint64_t value);
 
 /* The NUMA node the library believes its GPUs hang off (-1 = unknown, -2 = ask sysfs, the default).  Lets a one-node machine
@@ -182,15 +190,21 @@ void modgpu_debug_inject_failures(int count);
  * Stages: FILL = before the piece is copied / read into its slot; LAUNCH = filled, the kernel launch fails; SYNC = the wait for
  * the piece's kernel fails (what a GPU dying under way looks like); DRAIN = the kernel finished, the failure comes before the
  * piece is copied back; AFTER_DRAIN = the piece HAS been copied back, then the failure.  stage < 0 disarms.
- * STALL is not a failure of a HIP call but of the HOST: the pipeline thread sleeps for four times the host-fed kernel's patience
- * (MODGPU_TUNABLE_FEED_PATIENCE_MS) before it copies the piece in -- the kernel must give the call up by itself, and the call must
- * end like any other that lost its GPU under way (only calls that take the host-fed kernel have this stage). */
+ * STALL is not a failure of a HIP call but of the HOST: the pipeline thread holds the piece back until the host-fed kernel has
+ * given the call up by itself (its patience, MODGPU_TUNABLE_FEED_PATIENCE_MS, has run out and its stream has gone idle; bounded
+ * at two minutes) and only then copies it in -- the call must end like any other that lost its GPU under way.  Who reaches the
+ * piece first, kernel or pipeline, does not matter (only calls that take the host-fed kernel have this stage). */
 enum { MODGPU_STAGE_FILL = 0, MODGPU_STAGE_LAUNCH = 1, MODGPU_STAGE_SYNC = 2, MODGPU_STAGE_DRAIN = 3, MODGPU_STAGE_AFTER_DRAIN = 4, MODGPU_STAGE_STALL = 5 };
 #define MODGPU_INJECT_PIECE_LAST (-1)
 #define MODGPU_INJECT_PIECE_MIDDLE (-2)
 void modgpu_debug_inject_failure_at(int64_t piece, int stage);
 /* 1 while an armed failure has not fired yet. */
 int modgpu_debug_injection_armed(void);
+
+/* forbid != 0: no staging set starts a worker thread from now on, as if thread creation failed (a pids / NPROC limit).  A call that
+ * finds fewer workers than it has pipelines runs the rest itself, one after another -- and must not take a host-fed route, whose
+ * pipelines have to run side by side. */
+void modgpu_debug_forbid_worker_threads(int forbid);
 
 /* Takes `count` pipeline slots of `device`'s staging set the way a large call does and keeps them until called again with 0 (returns
  * how many it holds).  With all 32 held, a header-sized call must still be served -- from the two slots only one-slot calls may take. */

@@ -43,6 +43,7 @@ EXPORTS = {
     "modgpu_h2d": (_int, [_vp, _vp, _u64, _int]),
     "modgpu_d2h": (_int, [_vp, _vp, _u64, _int]),
     "modgpu_sync": (_int, [_int, _vp]),
+    "modgpu_prepare": (_int, [_int]),
     "modgpu_state_at": (ctypes.c_uint32, [_i32, _u64]),
     "modgpu_jump_table": (_int, [_int, ctypes.POINTER(ctypes.c_uint32), _int]),
     "modgpu_cycle_scalar_host": (_int, [_vp, _u64, _i32, _u64]),
@@ -85,7 +86,7 @@ HOST_TRACE_KINDS = ("call_begin", "slots", "posted", "pipe_start", "fill_begin",
 class LaunchInfo(ctypes.Structure):
     """modgpu_launch_info_t (include/modgpu_testing.h)."""
     _fields_ = [("kernel", ctypes.c_char_p), ("variant", _int), ("grid", ctypes.c_uint32), ("block", ctypes.c_uint32),
-                ("chunk_bytes", ctypes.c_uint32), ("bytes", _u64), ("main_groups", ctypes.c_uint32)]
+                ("chunk_bytes", ctypes.c_uint32), ("bytes", _u64), ("main_groups", ctypes.c_uint32), ("source_hash", ctypes.c_char_p)]
 
 
 # include/modgpu_testing.h, reporting group: in both flavours (measurement, not the drop-in boundary)
@@ -93,6 +94,7 @@ TESTING_EXPORTS = {
     "modgpu_time_cycle_device": (_int, [_vp, _u64, _i32, _u64, _int, _vp, _int, ctypes.POINTER(ctypes.c_float)]),
     "modgpu_last_launch": (_int, [ctypes.POINTER(LaunchInfo)]),
     "modgpu_kernel_source_hash": (ctypes.c_char_p, []),
+    "modgpu_feed_kernel_source_hash": (ctypes.c_char_p, []),
     "modgpu_host_tunables": (None, [ctypes.POINTER(_u64)]),
     "modgpu_host_chunking": (None, [ctypes.POINTER(_u64)]),
     "modgpu_host_loop_info": (None, [ctypes.POINTER(_u64)]),
@@ -120,6 +122,7 @@ DEBUG_EXPORTS = {
     "modgpu_debug_inject_failure_at": (None, [ctypes.c_int64, _int]),
     "modgpu_debug_injection_armed": (_int, []),
     "modgpu_debug_hold_slots": (_int, [_int, _int]),
+    "modgpu_debug_forbid_worker_threads": (None, [_int]),
 }
 
 
@@ -244,7 +247,8 @@ def last_launch():
     info = LaunchInfo()
     _check(lib().modgpu_last_launch(ctypes.byref(info)))
     return {"kernel": info.kernel.decode(), "variant": info.variant, "grid": info.grid, "block": info.block,
-            "chunk_bytes": info.chunk_bytes, "bytes": info.bytes, "main_groups": info.main_groups}
+            "chunk_bytes": info.chunk_bytes, "bytes": info.bytes, "main_groups": info.main_groups,
+            "source_hash": info.source_hash.decode() if info.source_hash else None}
 
 
 SHAPES = {None: -1, "auto": -1, "small": 0, "large": 1, "queue": 2}
@@ -267,7 +271,7 @@ def debug_set_staged_mode(mode=0):
 
 
 HOST_TUNABLES = {"zerocopy_bytes": 0, "ring": 1, "split": 2, "chunk_min_bytes": 3, "ramp_bytes": 4, "lanes": 5, "ntcopy": 6, "file_sched": 7,
-                 "feed": 8, "feed_chunk_bytes": 9, "feed_patience_ms": 10}
+                 "feed": 8, "feed_chunk_bytes": 9, "feed_patience_ms": 10, "file_feed": 11}
 
 
 def debug_set_host_tunable(name, value):
@@ -297,6 +301,11 @@ INJECT_PIECE_LAST, INJECT_PIECE_MIDDLE = -1, -2
 def debug_inject_failure_at(piece, stage):
     """Test hook: the HIP call of `stage` (STAGE_*) for piece `piece` of the next host-buffer / file call fails, once.  stage < 0 disarms."""
     _debug_lib().modgpu_debug_inject_failure_at(piece, stage)
+
+
+def debug_forbid_worker_threads(forbid=True):
+    """Testing flavour: staging sets start no worker thread from now on (as if thread creation failed)."""
+    _debug_lib().modgpu_debug_forbid_worker_threads(1 if forbid else 0)
 
 
 def debug_hold_slots(device, count):
@@ -406,8 +415,18 @@ def host_pool_stats():
             "calls_overlapped": int(out[3]), "slots_per_device": int(out[4]), "calls_on_another_nodes_set": int(out[5])}
 
 
+def prepare(device=-1):
+    """modgpu_prepare: device preparation + the empty wake-up launch, for callers that bring their own device memory."""
+    _check(lib().modgpu_prepare(device))
+
+
 def kernel_source_hash():
     return lib().modgpu_kernel_source_hash().decode()
+
+
+def feed_kernel_source_hash():
+    """identity of the host-fed kernel's TU (cycle_feed_kernel.hip and what it includes)"""
+    return lib().modgpu_feed_kernel_source_hash().decode()
 
 
 class PinnedBuffer:

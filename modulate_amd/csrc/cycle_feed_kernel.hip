@@ -17,7 +17,15 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 // counting the piece of the trip before, then drawing the next ticket and waiting for its chunk.  (A second thread-0 region
 // behind the trip's last barrier had the compiler send lanes 1..63 of wave 0 round the back edge on their own: that wave then
 // passed the barrier twice per trip, the other waves once, and the workgroup hung -- found in the lab form of this kernel,
-// tools/ubench_pcie_persist.hip.)
+// tools/ubench_pcie_persist.hip.)  Two things keep that from coming back with a compiler's mood: what decides whether a wave
+// goes round again (the ticket, the ok word) is read out of LDS into SCALAR registers (readfirstlane), so the back edge is a
+// scalar branch that a wave takes whole or not at all; and check_isa.py follows the compiled kernel's control flow and refuses
+// a build in which either s_barrier can be reached with anything but the EXEC mask the wave entered the loop with.
+//
+// Leaving: a workgroup's wait for a chunk ends when the host raises `abort`, when its patience runs out, or when ANOTHER
+// workgroup has already given up (work[1] != 0): the tickets that one held are lost, the call cannot be completed by this
+// kernel any more, and everybody who would otherwise wait out a patience of their own leaves at once -- the host starts its
+// rescue one patience after it went away, not two.
 __global__ __launch_bounds__(256) void modgpu_cycle_feed_kernel(CycleFeedArgs a)
 {
     __shared__ uint32_t s_t, s_ok;
@@ -41,8 +49,9 @@ __global__ __launch_bounds__(256) void modgpu_cycle_feed_kernel(CycleFeedArgs a)
                 counted = c;
                 const uint64_t since = wall_clock64();
                 while (__hip_atomic_load(&a.ready[c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
-                    // the two exits every waiting wave reaches: the host gives the call up, or does not turn up at all
-                    if (__hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || wall_clock64() - since > a.patience_ticks) {
+                    // the exits every waiting wave reaches: the host gives the call up, does not turn up at all, or a sibling has left already
+                    if (__hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || wall_clock64() - since > a.patience_ticks ||
+                        __hip_atomic_load(&a.work[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                         ok = 0;
                         break;
                     }
@@ -53,15 +62,17 @@ __global__ __launch_bounds__(256) void modgpu_cycle_feed_kernel(CycleFeedArgs a)
             s_ok = ok;
         }
         __syncthreads();
-        const uint32_t t = s_t, ok = s_ok;
+        // (the same value in every lane: held in scalar registers, the trip's control flow below is the whole wave's)
+        const uint32_t t = __builtin_amdgcn_readfirstlane(s_t), ok = __builtin_amdgcn_readfirstlane(s_ok);
         if (t >= n_tickets || !ok) {
             if (!ok && tid == 0) atomicAdd(&a.work[1], 1u);
             break;
         }
         const uint32_t c = t / tpc, piece = t - c * tpc;
-        const uint32_t slot = (c % a.pipes) * 2u + (c / a.pipes) % 2u;
-        uint8_t *const p = a.slot[slot] + (uint64_t)piece * kFeedPieceBytes;
         const uint64_t pos = (uint64_t)t * kFeedPieceBytes; // stream position of the piece's first byte
+        // where the piece lies: in its chunk's staging slot -- or, with pipes == 0, in place: the whole stream is contiguous at slot[0]
+        // (file -> page-locked destination: the host reads each chunk to where it belongs and the kernel cycles it there)
+        uint8_t *const p = a.pipes ? a.slot[(c % a.pipes) * 2u + (c / a.pipes) % 2u] + (uint64_t)piece * kFeedPieceBytes : a.slot[0] + pos;
         const uint32_t len = (uint32_t)(a.n - pos < kFeedPieceBytes ? a.n - pos : kFeedPieceBytes);
         const uint32_t words = len / lcg::WORD;
         // state of the piece's first byte: base * a^(32768 * t), by the three bytes of t
@@ -86,6 +97,13 @@ __global__ __launch_bounds__(256) void modgpu_cycle_feed_kernel(CycleFeedArgs a)
             st = mulmod_canon(st, c_tile_lo.v[words >> 8]);
             for (uint32_t k = 0; k < tid; ++k) st = mulmod_canon(st, lcg::A);
             uint8_t *const q = p + words * lcg::WORD + tid;
+            *q = cycle_byte(*q, st);
+        }
+        // (in place only) the < 16 bytes in front of the stream's first 16-byte boundary, with the first ticket
+        if (t == 0 && tid < a.head) {
+            uint32_t st = a.base_head;
+            for (uint32_t k = 0; k < tid; ++k) st = mulmod_canon(st, lcg::A);
+            uint8_t *const q = a.slot[0] - a.head + tid;
             *q = cycle_byte(*q, st);
         }
         __threadfence_system(); // this wave's stores have reached host memory ...

@@ -160,6 +160,10 @@ MODGPU_KNOB_STORAGE int kFileSched = MODGPU_KNOB("MODGPU_HOST_FILE_SCHED", 1, 0,
 // uniform chunks of feed_chunk bytes (no ramp needed: nothing is launched per chunk), marked ready / done through words in page-locked
 // memory.  profiles/r05_pcie_feed.txt.  0 (and staged mode 2 of the testing flavour): the launch-per-chunk schedule above.
 MODGPU_KNOB_STORAGE int kFeed = MODGPU_KNOB("MODGPU_HOST_FEED", 1, 0, 1);
+// file_feed: a FILE that ends in memory takes the host-fed kernel too (round 6): into pageable memory pread replaces the copy into the
+// slot; into page-locked memory the chunks are read to where they belong and the one kernel cycles them there (no slot, no copy).
+// 0 (testing flavour): round 5's launch per chunk.  profiles/r06_file_routes.txt.
+MODGPU_KNOB_STORAGE int kFileFeed = MODGPU_KNOB("MODGPU_HOST_FILE_FEED", 1, 0, 1);
 MODGPU_KNOB_STORAGE uint64_t kFeedChunk = (uint64_t)MODGPU_KNOB("MODGPU_HOST_FEED_CHUNK_KB", 256, 32, 8192) << 10;
 constexpr uint32_t kFeedChunksMax = 8192;      // ready / done words per call (larger calls take larger chunks)
 constexpr uint64_t kFeedBelow = 2ull << 30;    // from here up a launch per 8 MiB chunk is as good or better (4 GiB: 49.3 against 48.7 GB/s, profiles/r05_pcie_feed.txt)
@@ -409,6 +413,18 @@ int drain_slot(const Endpoint &dst, const uint8_t *pinned, uint64_t off, uint64_
     return MODGPU_OK;
 }
 
+// How a call's chunks get through the GPU.  One route per call; each is a pair of functions below (submit / wait) over the
+// shared pipeline core (run_route): the ring of slots, the order of steps, the failure rule and the copy out are the same for all.
+enum class Route {
+    dma,          // H2D DMA -> kernel in HBM -> D2H DMA, through device slots (page-locked caller memory on a side that is not cycled in
+                  // place; testing flavour: staged mode 1)
+    slot_kernel,  // copy / pread into a pinned slot -> ONE LAUNCH PER CHUNK across PCIe on the slot -> copy / pwrite out
+    in_dst,       // file -> page-locked caller memory: pread lands in the destination itself, a launch per chunk cycles it where it lies
+    feed,         // as slot_kernel, but ONE host-fed kernel for the whole call (cycle_feed_kernel.h): a pipeline marks its chunk ready
+                  // in page-locked memory and polls the chunk's done word
+    feed_in_dst,  // as in_dst, with the one host-fed kernel working in the destination (no slot, no copy, no launch per chunk)
+};
+
 // What a call knows about each piece of its stream.  The cipher is positional and the pieces are disjoint, so a call that loses
 // its GPU half-way can be FINISHED by the host loop over exactly the pieces whose result has not reached the destination
 // (the reference's Cycle cannot fail, CEncryptionCycler.cpp:4-14, and its callers do not guard it).
@@ -417,9 +433,7 @@ struct Job {
     uint64_t n, chunk; // chunk: the largest piece (slot size)
     int32_t key;
     uint64_t stream_off;
-    bool slot_kernel = false; // staged chunks are cycled in their pinned slot across PCIe (no DMA, no device slot)
-    bool in_dst = false;      // file -> page-locked caller memory: pread lands in the destination itself, which the kernel then
-                              // cycles where it lies across PCIe (no slot, no DMA, no copy)
+    Route route = Route::dma;
     std::atomic<bool> touched{false}; // the destination may differ from what it was
     std::atomic<bool> failed{false};  // a pipeline failed: the others stop filling and launching at once
     std::vector<Piece> plan;          // the stream cut into pieces, in stream order; piece k belongs to pipeline k mod pipes
@@ -427,7 +441,6 @@ struct Job {
     std::vector<hipStream_t> lanes; // kernels across PCIe are queued on these in launch order (empty: each on its slot's stream)
     std::atomic<uint64_t> launched{0};
     // host-fed call (cycle_feed_kernel.h): one kernel for the whole call; a pipeline marks a chunk ready instead of launching, and polls its done word
-    bool feed = false;
     uint32_t *feed_ready = nullptr, *feed_done = nullptr, *feed_abort = nullptr; // host addresses
     hipStream_t feed_stream = nullptr;
     std::atomic<bool> feed_launched{false}; // the kernel is on feed_stream (it is launched while the pipelines copy their first chunks in)
@@ -435,6 +448,9 @@ struct Job {
     cpu_set_t caller_mask; // the calling thread's affinity mask: a worker is never put on a CPU the caller may not use
     bool have_mask = false;
     Job(const Endpoint &s, const Endpoint &d, uint64_t n_, uint64_t chunk_, int32_t key_, uint64_t off_) : src(s), dst(d), n(n_), chunk(chunk_), key(key_), stream_off(off_) {}
+    bool fed() const { return route == Route::feed || route == Route::feed_in_dst; }
+    // the device writes the caller's destination itself (DMA or a kernel in place): an unfinished piece of it is undefined
+    bool dst_written_by_device() const { return (dst.mem && dst.pinned) || route == Route::in_dst || route == Route::feed_in_dst; }
     void set_plan(std::vector<Piece> p)
     {
         plan = std::move(p);
@@ -446,15 +462,21 @@ struct Job {
 // Cuts [0, n) into pieces of `chunk` bytes for `pipes` pipelines.  With a ramp the first and the last `pipes` pieces -- every
 // pipeline's first and last -- are only `ramp` bytes: the link carries nothing while the first pieces are copied into their slots
 // and nothing while the last are copied out, and that exposed time shrinks with them (profiles/r04_staged_midsize.txt).
-std::vector<Piece> cut_stream(uint64_t n, uint64_t chunk, int pipes, uint64_t ramp)
+// `head` bytes in front of the first piece belong to it (feed_in_dst: the kernel's chunks are counted from the destination's first
+// 16-byte boundary, the < 16 bytes in front of it travel with chunk 0).
+std::vector<Piece> cut_stream(uint64_t n, uint64_t chunk, int pipes, uint64_t ramp, uint64_t head = 0)
 {
     std::vector<Piece> plan;
     uint64_t at = 0;
     const uint64_t edge = (uint64_t)pipes * ramp;
-    const bool ramped = ramp > 0 && ramp < chunk && pipes > 1 && n >= 2 * edge + (uint64_t)pipes * chunk;
+    const bool ramped = ramp > 0 && ramp < chunk && pipes > 1 && n >= 2 * edge + (uint64_t)pipes * chunk && head == 0;
     if (ramped)
         for (int p = 0; p < pipes; ++p, at += ramp) plan.push_back({at, ramp});
     const uint64_t middle_end = ramped ? n - edge : n;
+    if (head && at < middle_end) {
+        plan.push_back({0, std::min<uint64_t>(head + chunk, middle_end)});
+        at = plan.back().len;
+    }
     for (; at < middle_end; at += chunk) plan.push_back({at, std::min<uint64_t>(chunk, middle_end - at)});
     if (ramped)
         for (at = middle_end; at < n; at += ramp) plan.push_back({at, std::min<uint64_t>(ramp, n - at)});
@@ -488,130 +510,241 @@ int feed_wait(Job &j, uint64_t c)
     return MODGPU_OK;
 }
 
-// One pipeline: chunks first, first+stride, ... of the stream through the `ring` slots slots[0..ring).
-// A pinned memory endpoint is DMA'd directly; anything else passes through the slot's pinned buffer.
+// ---- one pipeline -----------------------------------------------------------------------------------------------------------------
+// Chunks first, first + stride, ... of the stream through the `ring` slots slots[0..ring).
 // Failure: the pipeline that meets it raises j.failed, every pipeline sees that at its next step and stops; each waits for what
-// it has in flight and returns.  Pieces whose result had reached the destination are marked in j.done; nothing else of the
-// destination has been written by this route unless j.touched says so (see stream_impl for what that means per route).
-int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uint64_t stride)
-{
-    const int pipe = (int)first;
-    trace(MODGPU_TRACE_PIPE_START, pipe, 0, 0);
-    const uint64_t n_chunks = j.plan.size();
-    const bool src_direct = j.src.mem && j.src.pinned, dst_direct = j.dst.mem && j.dst.pinned;
-    auto span = [&](uint64_t c, uint64_t *off, uint64_t *len) {
-        *off = j.plan[c].off;
-        *len = j.plan[c].len;
-    };
-    const uint64_t mine = first < n_chunks ? (n_chunks - first + stride - 1) / stride : 0;
-    // kernels that work across PCIe (on the slot, or on the caller's page-locked destination) share the call's lanes
-    const bool on_lanes = !j.lanes.empty() && (j.slot_kernel || j.in_dst);
-    auto launch_across_pcie = [&](void *mapped, uint64_t len, uint64_t off, int slot) -> int {
+// it has in flight and returns.  Pieces whose result had reached the destination are marked in j.done.  THE INVARIANT the mid-call
+// rescue rests on: on the routes that pass through a slot (dma with a pageable destination, slot_kernel, feed) a piece changes
+// the caller's destination in exactly one place -- drain_slot in retire() below, after the piece's wait has succeeded -- and
+// j.touched is raised right in front of it; the routes on which the DEVICE writes the destination (dma into page-locked memory,
+// in_dst, feed_in_dst: Job::dst_written_by_device) raise it in their submit.
+struct Pipe {
+    Staging &s;
+    const int *slots;
+    int ring;
+    Job &j;
+    uint64_t first, stride;
+    int pipe;
+    uint64_t n_chunks, mine;
+    bool src_direct, dst_direct, on_lanes;
+    uint64_t chunk_of(uint64_t i) const { return first + i * stride; }
+    // a kernel that works across PCIe (on the slot, or on the caller's page-locked destination): on the call's shared lanes, if it has any
+    int launch_across_pcie(void *mapped, uint64_t len, uint64_t off, int slot)
+    {
         hipStream_t st = on_lanes ? j.lanes[j.launched.fetch_add(1, std::memory_order_relaxed) % j.lanes.size()] : s.stream[slot];
         int rc = cycle_device_impl(mapped, len, j.key, j.stream_off + off, st, /*over_pcie=*/true);
         if (rc == MODGPU_OK && on_lanes) HIP_TRY(hipEventRecord(s.event[slot], st));
         return rc;
-    };
-#define MODGPU_INJECT(piece, stage)                                                                                              \
-    do {                                                                                                                         \
-        if (injected_at((piece), n_chunks, (stage))) {                                                                           \
-            j.failed.store(true, std::memory_order_release); /* (before the trace line: what follows it in the log has seen it) */ \
-            trace(MODGPU_TRACE_FAILED, pipe, (piece), (uint64_t)(stage));                                                        \
-            return fail(MODGPU_ERR_HIP, "injected failure (modgpu_debug_inject_failure_at)");                                    \
-        }                                                                                                                        \
+    }
+    // (testing flavour) "the HIP call of `stage` for piece c fails": true once per arming; the caller returns the error
+    bool inject(uint64_t c, int stage)
+    {
+        if (!injected_at(c, n_chunks, stage)) return false;
+        j.failed.store(true, std::memory_order_release); // (before the trace line: what follows it in the log has seen it)
+        trace(MODGPU_TRACE_FAILED, pipe, c, (uint64_t)stage);
+        (void)fail(MODGPU_ERR_HIP, "injected failure (modgpu_debug_inject_failure_at)");
+        return true;
+    }
+};
+#define MODGPU_INJECT(p, piece, stage)                \
+    do {                                              \
+        if ((p).inject((piece), (stage))) return MODGPU_ERR_HIP; \
     } while (0)
-    auto step = [&](uint64_t i) -> int {
-        const int slot = slots[i % (uint64_t)ring];
-        if (j.failed.load(std::memory_order_acquire)) return kStopped;
-        if (i >= (uint64_t)ring) { // retire the chunk that used this slot `ring` trips ago
-            uint64_t off, len;
-            const uint64_t c = first + (i - ring) * stride;
-            span(c, &off, &len);
-            trace(MODGPU_TRACE_SYNC_BEGIN, pipe, c, len);
-            MODGPU_INJECT(c, MODGPU_STAGE_SYNC);
-            if (j.feed) {
-                const int rc = feed_wait(j, c);
-                if (rc) return rc;
-            } else if (on_lanes) HIP_TRY(hipEventSynchronize(s.event[slot]));
-            else HIP_TRY(hipStreamSynchronize(s.stream[slot]));
-            trace(MODGPU_TRACE_SYNC_END, pipe, c, len);
-            if (!dst_direct && !j.in_dst) {
-                MODGPU_INJECT(c, MODGPU_STAGE_DRAIN);
-                j.touched.store(true, std::memory_order_relaxed);
-                int rc = drain_slot(j.dst, s.pinned[slot], off, len);
-                trace(MODGPU_TRACE_DRAIN_END, pipe, c, len);
-                if (rc) return rc;
-            }
-            j.done[c].store(1, std::memory_order_release); // (a destination written directly -- DMA, or the kernel in place -- holds the piece once the wait has succeeded)
-            MODGPU_INJECT(c, MODGPU_STAGE_AFTER_DRAIN);
-            if (j.failed.load(std::memory_order_acquire)) return kStopped;
-        }
-        if (i < mine) {
-            uint64_t off, len;
-            const uint64_t c = first + i * stride;
-            span(c, &off, &len);
-            trace(MODGPU_TRACE_FILL_BEGIN, pipe, c, len);
-            MODGPU_INJECT(c, MODGPU_STAGE_FILL);
-            if (j.in_dst) {
-                j.touched.store(true, std::memory_order_relaxed);
-                int rc = fill_slot(j.src, j.dst.mem + off, off, len);
-                if (rc) return rc;
-                trace(MODGPU_TRACE_FILL_END, pipe, c, len);
-                MODGPU_INJECT(c, MODGPU_STAGE_LAUNCH);
-                void *mapped = nullptr;
-                HIP_TRY(hipHostGetDevicePointer(&mapped, j.dst.mem + off, 0));
-                rc = launch_across_pcie(mapped, len, off, slot);
-                trace(MODGPU_TRACE_LAUNCHED, pipe, c, len);
-                return rc;
-            }
-            if (j.slot_kernel) { // neither side is pinned caller memory: the slot itself is the device-visible copy
-                if (j.feed && injected_at(c, n_chunks, MODGPU_STAGE_STALL)) { // (testing flavour) the host goes away for a while: the kernel has to give up by itself
-                    trace(MODGPU_TRACE_FAILED, pipe, c, (uint64_t)MODGPU_STAGE_STALL);
-                    std::this_thread::sleep_for(std::chrono::microseconds(4 * kFeedPatienceTicks / 100));
-                }
-                int rc = fill_slot(j.src, s.pinned[slot], off, len);
-                if (rc) return rc;
-                trace(MODGPU_TRACE_FILL_END, pipe, c, len);
-                MODGPU_INJECT(c, MODGPU_STAGE_LAUNCH);
-                if (j.feed) { // the kernel is there already, waiting for exactly this
-                    __atomic_store_n(&j.feed_ready[c], 1u, __ATOMIC_RELEASE);
-                    trace(MODGPU_TRACE_READY, pipe, c, len);
-                    return MODGPU_OK;
-                }
-                void *mapped = nullptr;
-                HIP_TRY(hipHostGetDevicePointer(&mapped, s.pinned[slot], 0));
-                rc = launch_across_pcie(mapped, len, off, slot);
-                trace(MODGPU_TRACE_LAUNCHED, pipe, c, len);
-                return rc;
-            }
-            if (src_direct) {
-                HIP_TRY(hipMemcpyAsync(s.dev[slot], j.src.mem + off, len, hipMemcpyHostToDevice, s.stream[slot]));
-            } else {
-                int rc = fill_slot(j.src, s.pinned[slot], off, len);
-                if (rc) return rc;
-                HIP_TRY(hipMemcpyAsync(s.dev[slot], s.pinned[slot], len, hipMemcpyHostToDevice, s.stream[slot]));
-            }
-            trace(MODGPU_TRACE_FILL_END, pipe, c, len);
-            MODGPU_INJECT(c, MODGPU_STAGE_LAUNCH);
-            int rc = cycle_device_impl(s.dev[slot], len, j.key, j.stream_off + off, s.stream[slot]);
+
+// -- the routes: submit(p, c, slot) gets chunk c from the source to where the kernel works on it and has the kernel started (or
+//    told); wait(p, c, slot) returns once the chunk's result is whole -- in the slot, or in the destination on the direct routes.
+struct RouteDma {
+    static bool drains(const Pipe &p) { return !p.dst_direct; }
+    static int submit(Pipe &p, uint64_t c, int slot)
+    {
+        Job &j = p.j;
+        Staging &s = p.s;
+        const uint64_t off = j.plan[c].off, len = j.plan[c].len;
+        if (p.src_direct) {
+            HIP_TRY(hipMemcpyAsync(s.dev[slot], j.src.mem + off, len, hipMemcpyHostToDevice, s.stream[slot]));
+        } else {
+            int rc = fill_slot(j.src, s.pinned[slot], off, len);
             if (rc) return rc;
-            trace(MODGPU_TRACE_LAUNCHED, pipe, c, len);
-            if (dst_direct) {
-                j.touched.store(true, std::memory_order_relaxed);
-                HIP_TRY(hipMemcpyAsync(j.dst.mem + off, s.dev[slot], len, hipMemcpyDeviceToHost, s.stream[slot]));
-            } else {
-                HIP_TRY(hipMemcpyAsync(s.pinned[slot], s.dev[slot], len, hipMemcpyDeviceToHost, s.stream[slot]));
-            }
+            HIP_TRY(hipMemcpyAsync(s.dev[slot], s.pinned[slot], len, hipMemcpyHostToDevice, s.stream[slot]));
+        }
+        trace(MODGPU_TRACE_FILL_END, p.pipe, c, len);
+        MODGPU_INJECT(p, c, MODGPU_STAGE_LAUNCH);
+        int rc = cycle_device_impl(s.dev[slot], len, j.key, j.stream_off + off, s.stream[slot]);
+        if (rc) return rc;
+        trace(MODGPU_TRACE_LAUNCHED, p.pipe, c, len);
+        if (p.dst_direct) {
+            j.touched.store(true, std::memory_order_relaxed);
+            HIP_TRY(hipMemcpyAsync(j.dst.mem + off, s.dev[slot], len, hipMemcpyDeviceToHost, s.stream[slot]));
+        } else {
+            HIP_TRY(hipMemcpyAsync(s.pinned[slot], s.dev[slot], len, hipMemcpyDeviceToHost, s.stream[slot]));
         }
         return MODGPU_OK;
-    };
+    }
+    static int wait(Pipe &p, uint64_t, int slot)
+    {
+        HIP_TRY(hipStreamSynchronize(p.s.stream[slot]));
+        return MODGPU_OK;
+    }
+};
+struct RouteSlotKernel { // neither side is page-locked caller memory: the slot itself is the device-visible copy
+    static bool drains(const Pipe &) { return true; }
+    static int submit(Pipe &p, uint64_t c, int slot)
+    {
+        Job &j = p.j;
+        const uint64_t off = j.plan[c].off, len = j.plan[c].len;
+        int rc = fill_slot(j.src, p.s.pinned[slot], off, len);
+        if (rc) return rc;
+        trace(MODGPU_TRACE_FILL_END, p.pipe, c, len);
+        MODGPU_INJECT(p, c, MODGPU_STAGE_LAUNCH);
+        void *mapped = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&mapped, p.s.pinned[slot], 0));
+        rc = p.launch_across_pcie(mapped, len, off, slot);
+        trace(MODGPU_TRACE_LAUNCHED, p.pipe, c, len);
+        return rc;
+    }
+    static int wait(Pipe &p, uint64_t, int slot)
+    {
+        if (p.on_lanes) HIP_TRY(hipEventSynchronize(p.s.event[slot]));
+        else HIP_TRY(hipStreamSynchronize(p.s.stream[slot]));
+        return MODGPU_OK;
+    }
+};
+struct RouteInDst {
+    static bool drains(const Pipe &) { return false; }
+    static int submit(Pipe &p, uint64_t c, int slot)
+    {
+        Job &j = p.j;
+        const uint64_t off = j.plan[c].off, len = j.plan[c].len;
+        j.touched.store(true, std::memory_order_relaxed);
+        int rc = fill_slot(j.src, j.dst.mem + off, off, len);
+        if (rc) return rc;
+        trace(MODGPU_TRACE_FILL_END, p.pipe, c, len);
+        MODGPU_INJECT(p, c, MODGPU_STAGE_LAUNCH);
+        void *mapped = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&mapped, j.dst.mem + off, 0));
+        rc = p.launch_across_pcie(mapped, len, off, slot);
+        trace(MODGPU_TRACE_LAUNCHED, p.pipe, c, len);
+        return rc;
+    }
+    static int wait(Pipe &p, uint64_t c, int slot) { return RouteSlotKernel::wait(p, c, slot); }
+};
+// (testing flavour) the host goes away: the pipeline holds its chunk back UNTIL THE KERNEL HAS GIVEN THE CALL UP -- its stream has gone
+// idle with the chunk undone --, not for a time it guesses: who arrives at the chunk first, the kernel or the pipeline, is the box's
+// business (under TSan the stand-in kernel needs > 100 ms to get there), and the case is "the kernel waits and nobody comes" either
+// way.  Bounded, so that a kernel that never leaves shows up as the call's own failure further down, not as a hung test.
+void stall_until_the_kernel_has_left(Pipe &p, uint64_t c)
+{
+    Job &j = p.j;
+    if (!j.fed() || !injected_at(c, p.n_chunks, MODGPU_STAGE_STALL)) return;
+    trace(MODGPU_TRACE_FAILED, p.pipe, c, (uint64_t)MODGPU_STAGE_STALL);
+    const auto until = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+    while (std::chrono::steady_clock::now() < until && !j.failed.load(std::memory_order_acquire)) {
+        if (j.feed_launched.load(std::memory_order_acquire)) {
+            if (hipStreamQuery(j.feed_stream) != hipErrorNotReady) break;
+            (void)hipGetLastError();
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+}
+struct RouteFeed { // the kernel is there already, waiting for exactly this chunk's ready word
+    static bool drains(const Pipe &) { return true; }
+    static int submit(Pipe &p, uint64_t c, int slot)
+    {
+        Job &j = p.j;
+        const uint64_t off = j.plan[c].off, len = j.plan[c].len;
+        stall_until_the_kernel_has_left(p, c);
+        int rc = fill_slot(j.src, p.s.pinned[slot], off, len);
+        if (rc) return rc;
+        trace(MODGPU_TRACE_FILL_END, p.pipe, c, len);
+        MODGPU_INJECT(p, c, MODGPU_STAGE_LAUNCH);
+        __atomic_store_n(&j.feed_ready[c], 1u, __ATOMIC_RELEASE);
+        trace(MODGPU_TRACE_READY, p.pipe, c, len);
+        return MODGPU_OK;
+    }
+    static int wait(Pipe &p, uint64_t c, int) { return feed_wait(p.j, c); }
+};
+struct RouteFeedInDst { // ... and works where the chunk was read to: the caller's page-locked destination
+    static bool drains(const Pipe &) { return false; }
+    static int submit(Pipe &p, uint64_t c, int)
+    {
+        Job &j = p.j;
+        const uint64_t off = j.plan[c].off, len = j.plan[c].len;
+        stall_until_the_kernel_has_left(p, c);
+        j.touched.store(true, std::memory_order_relaxed);
+        int rc = fill_slot(j.src, j.dst.mem + off, off, len);
+        if (rc) return rc;
+        trace(MODGPU_TRACE_FILL_END, p.pipe, c, len);
+        MODGPU_INJECT(p, c, MODGPU_STAGE_LAUNCH);
+        __atomic_store_n(&j.feed_ready[c], 1u, __ATOMIC_RELEASE);
+        trace(MODGPU_TRACE_READY, p.pipe, c, len);
+        return MODGPU_OK;
+    }
+    static int wait(Pipe &p, uint64_t c, int) { return feed_wait(p.j, c); }
+};
+
+// -- the core every route runs on: step i retires the chunk that used this step's slot `ring` steps ago, then submits chunk i
+template <class R> int retire(Pipe &p, uint64_t c, int slot)
+{
+    Job &j = p.j;
+    const uint64_t off = j.plan[c].off, len = j.plan[c].len;
+    trace(MODGPU_TRACE_SYNC_BEGIN, p.pipe, c, len);
+    MODGPU_INJECT(p, c, MODGPU_STAGE_SYNC);
+    int rc = R::wait(p, c, slot);
+    if (rc) return rc;
+    trace(MODGPU_TRACE_SYNC_END, p.pipe, c, len);
+    if (R::drains(p)) {
+        MODGPU_INJECT(p, c, MODGPU_STAGE_DRAIN);
+        j.touched.store(true, std::memory_order_relaxed);
+        rc = drain_slot(j.dst, p.s.pinned[slot], off, len); // THE place a slot route writes the caller's destination
+        trace(MODGPU_TRACE_DRAIN_END, p.pipe, c, len);
+        if (rc) return rc;
+    }
+    j.done[c].store(1, std::memory_order_release); // (a destination written directly -- DMA, or the kernel in place -- holds the piece once the wait has succeeded)
+    MODGPU_INJECT(p, c, MODGPU_STAGE_AFTER_DRAIN);
+    return MODGPU_OK;
+}
+template <class R> int run_route(Pipe &p)
+{
+    Job &j = p.j;
+    for (uint64_t i = 0; i < p.mine + (uint64_t)p.ring; ++i) {
+        const int slot = p.slots[i % (uint64_t)p.ring];
+        if (j.failed.load(std::memory_order_acquire)) return kStopped;
+        if (i >= (uint64_t)p.ring) {
+            const int rc = retire<R>(p, p.chunk_of(i - (uint64_t)p.ring), slot);
+            if (rc) return rc;
+            if (j.failed.load(std::memory_order_acquire)) return kStopped;
+        }
+        if (i < p.mine) {
+            const uint64_t c = p.chunk_of(i);
+            trace(MODGPU_TRACE_FILL_BEGIN, p.pipe, c, j.plan[c].len);
+            MODGPU_INJECT(p, c, MODGPU_STAGE_FILL);
+            const int rc = R::submit(p, c, slot);
+            if (rc) return rc;
+        }
+    }
+    return MODGPU_OK;
+}
 #undef MODGPU_INJECT
+
+int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uint64_t stride)
+{
+    const uint64_t n_chunks = j.plan.size();
+    Pipe p{s, slots, ring, j, first, stride, (int)first, n_chunks, first < n_chunks ? (n_chunks - first + stride - 1) / stride : 0,
+           j.src.mem && j.src.pinned, j.dst.mem && j.dst.pinned,
+           !j.lanes.empty() && (j.route == Route::slot_kernel || j.route == Route::in_dst)};
+    trace(MODGPU_TRACE_PIPE_START, p.pipe, 0, 0);
     int rc = MODGPU_OK;
-    for (uint64_t i = 0; i < mine + (uint64_t)ring && rc == MODGPU_OK; ++i) rc = step(i);
+    switch (j.route) {
+    case Route::dma: rc = run_route<RouteDma>(p); break;
+    case Route::slot_kernel: rc = run_route<RouteSlotKernel>(p); break;
+    case Route::in_dst: rc = run_route<RouteInDst>(p); break;
+    case Route::feed: rc = run_route<RouteFeed>(p); break;
+    case Route::feed_in_dst: rc = run_route<RouteFeedInDst>(p); break;
+    }
     if (rc != MODGPU_OK) { // nothing of this call may still be running against the caller's memory (or its slots) once we return
         if (rc != kStopped) j.failed.store(true, std::memory_order_release);
         const std::string keep = t_err;
-        if (j.feed) { // the kernel leaves at its next look at the flag; chunks it has not finished stay undone
+        if (j.fed()) { // the kernel leaves at its next look at the flag; chunks it has not finished stay undone
             __atomic_store_n(j.feed_abort, 1u, __ATOMIC_RELEASE);
             (void)hipStreamSynchronize(j.feed_stream);
         }
@@ -620,7 +753,7 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
         (void)hipGetLastError();
         t_err = keep;
     }
-    trace(MODGPU_TRACE_PIPE_END, pipe, 0, 0);
+    trace(MODGPU_TRACE_PIPE_END, p.pipe, 0, 0);
     return rc;
 }
 
@@ -680,24 +813,41 @@ void worker_main(Staging *s, int logical, int phys, cpu_set_t allowed, bool have
     }
 }
 
-// Posts `extra` pipelines of `call` to the device's workers, starting workers the pool is short of (never more than
-// kMaxPipes - 1 per device; if a thread cannot be started the caller simply runs more of the pipelines itself).
-void post_to_workers(Staging &s, const std::shared_ptr<Call> &call, int extra, int logical)
+// Makes sure the staging set has `want` worker threads (never more than kMaxPipes - 1 per set) and returns how many it has.  A
+// thread that cannot be started (a pids or NPROC limit) is not an error: the caller runs more of the pipelines itself, one after
+// another -- which every launch-per-chunk route is fine with, and the host-fed routes are NOT (their kernel draws chunks in stream
+// order and waits for whichever pipeline owns the next one: pipelines that run one after another would leave it waiting out its
+// patience).  So stream_impl asks BEFORE it decides on a host-fed route.
+#ifdef MODGPU_TESTING_HOOKS
+std::atomic<int> g_forbid_spawn{0}; // modgpu_debug_forbid_worker_threads
+#endif
+int ensure_workers(Staging &s, int want, int logical, int phys, const cpu_set_t &mask, bool have_mask)
+{
+#ifdef MODGPU_TESTING_HOOKS
+    if (g_forbid_spawn.load(std::memory_order_relaxed)) return 0; // "no thread can be had": nothing is started, nothing posted
+#endif
+    std::lock_guard<std::mutex> lock(s.mu);
+    want = std::min(want, kMaxPipes - 1);
+    while (s.workers < want) {
+        try {
+            std::thread(worker_main, &s, logical, phys, mask, have_mask).detach();
+            ++s.workers;
+            g_pool_spawned.fetch_add(1, std::memory_order_relaxed);
+        } catch (...) {
+            break;
+        }
+    }
+    return s.workers;
+}
+
+// Posts `extra` pipelines of `call` to the set's workers (ensure_workers has started them; entries no worker picks up are run by the
+// caller itself).
+void post_to_workers(Staging &s, const std::shared_ptr<Call> &call, int extra)
 {
     if (extra <= 0) return;
     {
         std::lock_guard<std::mutex> lock(s.mu);
         for (int k = 0; k < extra; ++k) s.requests.push_back(call);
-        const int short_of = (int)s.requests.size() - s.parked;
-        for (int k = 0; k < short_of && s.workers < kMaxPipes - 1; ++k) {
-            try {
-                std::thread(worker_main, &s, logical, call->phys, call->job.caller_mask, call->job.have_mask).detach();
-                ++s.workers;
-                g_pool_spawned.fetch_add(1, std::memory_order_relaxed);
-            } catch (...) {
-                break;
-            }
-        }
     }
     s.work_cv.notify_all();
 }
@@ -768,6 +918,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     // which of the device's staging sets: the one on the node the caller's PAGEABLE pages live on, if that is not the GPU's own
     int copy_node = -1;
     cpu_set_t caller_mask;
+    CPU_ZERO(&caller_mask);
     bool have_mask = false;
     if (numa::enabled() && n > kZeroCopyMax) {
         const uint8_t *pages = src.mem && !src_direct ? src.mem : dst.mem && !dst_direct ? dst.mem : nullptr;
@@ -859,25 +1010,35 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     uint64_t chunk = n <= chunk_min ? std::max<uint64_t>(n, 1ull << 20)
                                     : std::min<uint64_t>(kChunk, std::max<uint64_t>(chunk_min, ((n / split) + 0xFFFFF) & ~0xFFFFFull));
     chunk = std::min<uint64_t>(chunk, kChunk);
-    // Pageable memory on both sides: ONE host-fed kernel for the whole call (cycle_feed_kernel.h).  Uniform chunks -- as small as the
-    // flag words allow, since no chunk costs a launch -- of whole pieces; a call too large for that (or staged mode 1 / 2 of the testing
-    // flavour, or feed switched off) keeps the launch-per-chunk schedule.
-    bool feed = kFeed != 0 && staged_mode() == 0 && src.mem && dst.mem && !src_direct && !dst_direct && !identity;
-    if (feed) {
+    // Default routes (profiles/r03_file_routes.txt, r06_file_routes.txt): pageable memory and files are copied / read into a pinned
+    // slot and cycled there across PCIe; a file that ends in page-locked caller memory is read straight into that memory and cycled
+    // where it lies; page-locked caller memory that ends in a file is DMA'd.  (Testing flavour, staged mode 1: the DMA form -- H2D,
+    // kernel in HBM, D2H -- of the first two.)
+    Route route = dst_direct && !src.mem && !identity && staged_mode() != 1 ? Route::in_dst
+                  : !src_direct && !dst_direct && staged_mode() != 1        ? Route::slot_kernel
+                                                                            : Route::dma;
+    // A pageable (or file) source that ends in memory: ONE host-fed kernel for the whole call (cycle_feed_kernel.h) instead of a launch
+    // per chunk.  Uniform chunks -- as small as the flag words allow, since no chunk costs a launch -- of whole pieces; a call too large
+    // for that (or staged mode 1 / 2 of the testing flavour, or feed switched off) keeps the launch-per-chunk schedule.  The kernel draws
+    // chunks in stream order and waits for whichever pipeline owns the next one, so the pipelines must really run side by side: a
+    // staging set that cannot have its worker threads does not take these routes.
+    const bool feedable = kFeed != 0 && staged_mode() == 0 && !identity && dst.mem && (src.mem ? !src_direct && !dst_direct : kFileFeed != 0);
+    uint64_t head = 0; // feed_in_dst: bytes of the destination in front of its first 16-byte boundary (they travel with chunk 0)
+    if (feedable && (route == Route::slot_kernel || route == Route::in_dst)) {
         const uint64_t piece = kFeedPieceBytes;
         const uint64_t c = std::max<uint64_t>((kFeedChunk + piece - 1) / piece * piece, ((n + kFeedChunksMax - 1) / kFeedChunksMax + piece - 1) / piece * piece);
-        if (c > kChunk || (n + piece - 1) / piece >= kFeedPiecesMax || n >= kFeedBelow) feed = false;
-        else chunk = c;
+        const int pipes_wanted = (int)std::min<uint64_t>((uint64_t)kPipes, ((n + c - 1) / c + 1) / 2);
+        if (route == Route::in_dst) head = (16 - (reinterpret_cast<uintptr_t>(dst.mem) & 15)) & 15;
+        if (c <= kChunk && (n + piece - 1) / piece < kFeedPiecesMax && (n < kFeedBelow || route == Route::in_dst) && n > head + piece &&
+            (pipes_wanted <= 1 || ensure_workers(s, pipes_wanted - 1, dev, physical_of(dev), caller_mask, have_mask) >= pipes_wanted - 1)) {
+            chunk = c;
+            route = route == Route::in_dst ? Route::feed_in_dst : Route::feed;
+        } else head = 0;
     }
-    const uint64_t n_chunks = (n + chunk - 1) / chunk;
+    const bool feed = route == Route::feed || route == Route::feed_in_dst;
+    const uint64_t n_chunks = (n - head + chunk - 1) / chunk;
     Job job(src, dst, n, chunk, key, stream_off);
-    // Default routes (profiles/r03_file_routes.txt): pageable memory and files are copied / read into a pinned slot and
-    // cycled there across PCIe; a file that ends in page-locked caller memory is read straight into that memory and cycled
-    // where it lies; page-locked caller memory that ends in a file is DMA'd.  (Testing flavour, staged mode 1: the DMA
-    // form -- H2D, kernel in HBM, D2H -- of the first two.)
-    job.slot_kernel = !src_direct && !dst_direct && staged_mode() != 1;
-    job.feed = feed;
-    job.in_dst = dst_direct && !src.mem && !identity && staged_mode() != 1;
+    job.route = route;
     int pipes, ring;
     if (all_direct && src.mem && dst.mem) { // no host work at all: one thread keeps a ring of slots busy
         pipes = 1;
@@ -894,13 +1055,14 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     SlotLease lease(s);
     lease.acquire(pipes * ring, ring);
     pipes = (int)lease.ids.size() / ring;
-    job.set_plan(cut_stream(n, chunk, pipes, mem_both && !feed ? kRamp : 0));
+    job.set_plan(cut_stream(n, chunk, pipes, mem_both && !feed ? kRamp : 0, head));
     job.copy_node = copy_node;
     job.have_mask = have_mask;
     if (have_mask) job.caller_mask = caller_mask;
     for (int k = 0; k < (feed ? 0 : mem_both ? kLanes : kFileLanes) && k < (int)lease.ids.size(); ++k) job.lanes.push_back(nullptr); // (streams exist after staging_reserve)
     trace(MODGPU_TRACE_SLOTS, -1, (uint64_t)pipes, chunk);
-    rc = staging_reserve(s, lease.ids, chunk, !job.slot_kernel && !job.in_dst, !(src_direct && dst_direct) && !job.in_dst);
+    const bool works_in_dst = route == Route::in_dst || route == Route::feed_in_dst;
+    rc = staging_reserve(s, lease.ids, chunk, route == Route::dma, !(src_direct && dst_direct) && !works_in_dst);
     if (rc) return rc;
     for (size_t k = 0; k < job.lanes.size(); ++k) job.lanes[k] = s.stream[lease.ids[k]];
     // Host-fed call: the flag words are cleared and handed to the pipelines BEFORE these start; the launch itself (~15 us of host time)
@@ -910,17 +1072,23 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     uint64_t feed_chunks = 0;
     auto launch_feed = [&]() -> int {
         CycleFeedArgs a{};
-        for (int k = 0; k < pipes * ring; ++k) HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&a.slot[k]), s.pinned[lease.ids[(size_t)k]], 0));
+        if (route == Route::feed_in_dst) { // the chunks are read to where they belong: the kernel's stream starts at the destination's first 16-byte boundary
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&a.slot[0]), dst.mem, 0));
+            a.slot[0] += head;
+        } else
+            for (int k = 0; k < pipes * ring; ++k) HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&a.slot[k]), s.pinned[lease.ids[(size_t)k]], 0));
         a.ready = s.feed_flags_dev[lead_slot];
         a.done = s.feed_flags_dev[lead_slot] + kFeedChunksMax;
         a.abort = s.feed_flags_dev[lead_slot] + 2 * kFeedChunksMax;
         a.work = s.feed_work[lead_slot]; // (all zero: feed_reserve, feed_leave_clean)
-        a.n = n;
+        a.n = n - head;
         a.patience_ticks = kFeedPatienceTicks;
         a.chunk_bytes = (uint32_t)chunk;
-        a.pipes = (uint32_t)pipes;
-        a.base = lcg::state_residue(lcg::key_residue(key), stream_off);
-        const uint32_t pieces = (uint32_t)((n + kFeedPieceBytes - 1) / kFeedPieceBytes);
+        a.pipes = route == Route::feed_in_dst ? 0u : (uint32_t)pipes;
+        a.head = (uint32_t)head;
+        a.base_head = lcg::state_residue(lcg::key_residue(key), stream_off);
+        a.base = lcg::state_residue(lcg::key_residue(key), stream_off + head);
+        const uint32_t pieces = (uint32_t)((n - head + kFeedPieceBytes - 1) / kFeedPieceBytes);
         const uint32_t grid = std::min<uint32_t>(kFeedGrid, pieces);
         const hipError_t e = modgpu_launch_cycle_feed(a, grid, job.feed_stream);
         if (e != hipSuccess) return fail_hip(e, "cycle kernel launch (host-fed)");
@@ -953,7 +1121,8 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
         if (rc == kStopped) rc = MODGPU_OK;
     } else {
         auto call = std::make_shared<Call>(s, job, pipes, ring, physical_of(dev), lease.ids);
-        post_to_workers(s, call, pipes - 1, dev);
+        const int workers = ensure_workers(s, pipes - 1, dev, physical_of(dev), caller_mask, have_mask);
+        post_to_workers(s, call, std::min(pipes - 1, workers)); // (pipelines nobody is there for are run by this thread, after its own)
         trace(MODGPU_TRACE_POSTED, -1, (uint64_t)pipes, 0);
         int rc_launch = MODGPU_OK;
         std::string launch_err;
@@ -1010,8 +1179,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     // as long as its plaintext is still somewhere: in the source file, in the caller's other buffer, or in the destination itself
     // when that is only ever written by a finished piece's copy out of its slot (the staged route).  In place AND written
     // directly by the device (page-locked memory in DMA mode) the plaintext of an unfinished piece is gone: the error stands.
-    const bool dst_written_by_device = dst_direct || job.in_dst;
-    const bool recoverable = rc == MODGPU_ERR_HIP && !(in_place && dst_written_by_device);
+    const bool recoverable = rc == MODGPU_ERR_HIP && !(in_place && job.dst_written_by_device());
     if (!host_may_finish || !recoverable) return rc;
     const std::string why = t_err;
     uint64_t host_bytes = 0;
@@ -1052,6 +1220,7 @@ void modgpu_debug_inject_failure_at(int64_t piece, int stage)
     g_inject_piece.store(piece, std::memory_order_relaxed);
     g_inject_stage.store(stage >= MODGPU_STAGE_FILL && stage <= MODGPU_STAGE_STALL ? stage : -1, std::memory_order_release);
 }
+void modgpu_debug_forbid_worker_threads(int forbid) { g_forbid_spawn.store(forbid ? 1 : 0); }
 int modgpu_debug_injection_armed(void) { return g_inject_stage.load(std::memory_order_acquire) >= 0 ? 1 : 0; }
 // Takes `count` PIPELINE slots of a device's own staging set, as large calls do, and keeps them until called with count = 0: with all
 // of them held, what a header-sized call still finds is exactly the slots reserved for it.  Returns how many are held now.
@@ -1082,6 +1251,7 @@ void modgpu_debug_set_host_tunable(int which, uint64_t value)
     case MODGPU_TUNABLE_FILE_SCHED: kFileSched = value != 0; break;
     case MODGPU_TUNABLE_FEED: kFeed = value != 0; break;
     case MODGPU_TUNABLE_FEED_CHUNK_BYTES: kFeedChunk = clamp(value, 32ull << 10, 8ull << 20); break;
+    case MODGPU_TUNABLE_FILE_FEED: kFileFeed = value != 0; break;
     case MODGPU_TUNABLE_FEED_PATIENCE_MS: kFeedPatienceTicks = clamp(value, 1, 600000) * 100000ull; break;
     default: break;
     }

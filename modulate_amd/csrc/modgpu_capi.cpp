@@ -579,7 +579,7 @@ int launch_queue(void *const *bufs, const uint64_t *sizes, const uint64_t *offs,
         g_batch_launches.fetch_add(1, std::memory_order_relaxed);
         g_batch_parts.fetch_add((uint64_t)n, std::memory_order_relaxed);
     }
-    t_last_launch = {modgpu_queue_kernel_name(), n > 1 ? CYCLE_BATCH : CYCLE_QUEUE, grid, modgpu_queue_block(), (uint32_t)chunk, bytes, (uint32_t)main_groups};
+    t_last_launch = {modgpu_queue_kernel_name(), n > 1 ? CYCLE_BATCH : CYCLE_QUEUE, grid, modgpu_queue_block(), (uint32_t)chunk, bytes, (uint32_t)main_groups, MODGPU_KERNEL_SOURCE_HASH};
     return MODGPU_OK;
 }
 
@@ -602,14 +602,14 @@ int cycle_device_impl(void *dev_buf, uint64_t n, int32_t key, uint64_t stream_of
     if (e != hipSuccess) return fail_hip(e, "cycle kernel launch");
     g_stats.gpu_launches.fetch_add(1, std::memory_order_relaxed);
     t_last_launch = {modgpu_variant_kernel_name(p.variant), p.variant, p.grid, modgpu_variant_block(p.variant),
-                     modgpu_variant_chunk_bytes(p.variant), n, p.grid};
+                     modgpu_variant_chunk_bytes(p.variant), n, p.grid, MODGPU_KERNEL_SOURCE_HASH};
     return MODGPU_OK;
 }
 
 void note_feed_launch(uint32_t grid, uint64_t bytes)
 {
     g_stats.gpu_launches.fetch_add(1, std::memory_order_relaxed);
-    t_last_launch = {modgpu_feed_kernel_name(), CYCLE_FEED, grid, modgpu_feed_block(), kFeedPieceBytes, bytes, grid};
+    t_last_launch = {modgpu_feed_kernel_name(), CYCLE_FEED, grid, modgpu_feed_block(), kFeedPieceBytes, bytes, grid, MODGPU_FEED_KERNEL_SOURCE_HASH};
 }
 
 // n_parts buffers resident on the CURRENT device, each its own Cycle call (keystream from offs[i], or 0), asynchronous on
@@ -1293,20 +1293,25 @@ int modgpu_free(void *dev_ptr, int device)
 // STARTS, an empty launch (zero words, one workgroup) goes to a stream of the library's own that nobody waits for, so the engines
 // wake while the DMA engine works.  Measured: first launch after a 1.5 s pause + upload 0.1420 -> 0.1262 ms at 411 MB, which is
 // the size's own rate (0.1261).  Best effort; costs the caller one asynchronous launch call per copy of 1 MiB or more.
-static void wake_shader_engines(int logical)
+static void wake_shader_engines()
 {
     static std::mutex mu;
-    static hipStream_t streams[kMaxDevices] = {};
-    if (logical < 0 || logical >= kMaxDevices) return;
+    static hipStream_t streams[kMaxDevices] = {}; // by PHYSICAL device: a stream belongs to the device it was created on, whatever logical
+                                                  // index (MODGPU_DEVICE_ALIAS) or "current device" (-1) the caller named it by
+    int phys = -1;
+    if (hipGetDevice(&phys) != hipSuccess || phys < 0 || phys >= kMaxDevices) {
+        (void)hipGetLastError();
+        return;
+    }
     hipStream_t st;
     {
         std::lock_guard<std::mutex> lock(mu);
-        if (!streams[logical] && hipStreamCreateWithFlags(&streams[logical], hipStreamNonBlocking) != hipSuccess) {
+        if (!streams[phys] && hipStreamCreateWithFlags(&streams[phys], hipStreamNonBlocking) != hipSuccess) {
             (void)hipGetLastError();
-            streams[logical] = nullptr;
+            streams[phys] = nullptr;
             return;
         }
-        st = streams[logical];
+        st = streams[phys];
     }
     CycleArgs a{}; // no head, no words, no tail: the one workgroup finds nothing to do
     a.base_head = a.base_body = a.base_tail = 1;
@@ -1320,11 +1325,19 @@ int modgpu_h2d(void *dev_dst, const void *host_src, uint64_t n, int device)
     return guarded([&]() -> int {
         DeviceScope scope(device);
         if (scope.rc) return scope.rc;
-        if (n >= (1ull << 20)) {
-            int logical = device;
-            if (logical >= 0 || hipGetDevice(&logical) == hipSuccess) wake_shader_engines(logical);
-        }
+        if (n >= (1ull << 20)) wake_shader_engines(); // (the scope has made the device current)
         if (n) HIP_TRY(hipMemcpy(dev_dst, host_src, n, hipMemcpyHostToDevice));
+        return MODGPU_OK;
+    });
+}
+
+int modgpu_prepare(int device)
+{
+    return guarded([&]() -> int {
+        DeviceScope scope(device);
+        if (scope.rc) return scope.rc;
+        prepare_device();      // once per device and process: code object, ticket ring, the first real work-queue launches
+        wake_shader_engines(); // every call: one empty launch on a private stream nobody waits for
         return MODGPU_OK;
     });
 }
@@ -1439,6 +1452,7 @@ void modgpu_queue_stats(uint64_t out[6])
 }
 
 const char *modgpu_kernel_source_hash(void) { return MODGPU_KERNEL_SOURCE_HASH; }
+const char *modgpu_feed_kernel_source_hash(void) { return MODGPU_FEED_KERNEL_SOURCE_HASH; }
 
 int modgpu_testing_hooks(void)
 {

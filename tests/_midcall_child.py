@@ -4,7 +4,9 @@ call that has already begun, and the reference's contract -- Cycle cannot fail, 
 CArk.cpp:338-339, 1135-1136, Modulate.cpp:485-486 -- has to hold: modgpu_cycle_auto_host and CEncryptionCycler::Cycle return the
 reference's bytes, the strict entry points and MODGPU_REQUIRE_GPU=1 return the error.
 
-    python tests/_midcall_child.py <MiB>[,<MiB>...] [--class] [--files DIR]
+    python tests/_midcall_child.py <MiB>[,<MiB>...] [--class] [--files DIR] [--only-stall]
+
+--only-stall: just the case in which the HOST goes away (the one that used to depend on the clock).
 
 Needs MODGPU_MIN_GPU_BYTES below the sizes used.  Prints MIDCALL_OK <strict> at the end."""
 import os
@@ -37,7 +39,8 @@ def cycle(buf):
         M.cycle_auto_host(buf, M.KEY_PS4)
 
 
-for n in sizes:
+only_stall = "--only-stall" in sys.argv
+for n in ([] if only_stall else sizes):
     pt = O.splitmix_bytes(min(n, 64 << 20), 8)
     pt = np.resize(pt, n)
     want = pt.copy()
@@ -91,18 +94,26 @@ for n in sizes:
     cycle(buf)
     assert np.array_equal(buf, want) and M.path_stats()["midcall_rescues"] == before["midcall_rescues"]
 
-# ---- not the GPU but the HOST goes away: a pipeline thread stalls for four times the host-fed kernel's patience before it copies its piece
-# in.  The kernel must give the call up by itself (every workgroup that waits for that chunk leaves, the others run out of tickets), the
-# pipeline finds the kernel gone and the chunk undone, and the call ends like any other that lost its GPU under way.
+# ---- not the GPU but the HOST goes away: a pipeline thread holds its piece back until the host-fed kernel has given the call up by itself
+# (testing flavour: it polls the kernel's stream; who reaches the piece first, kernel or pipeline, does not matter -- VERDICT r5 weak #3: the
+# round-5 form slept for 4 x patience from its own arrival and lost the race against a slowed stand-in).  The first workgroup whose patience
+# runs out says so, every other one leaves at its next wait, the pipeline finds the kernel gone and the chunk undone, and the call ends like
+# any other that lost its GPU under way -- one patience after the host went away, not two.
 import time  # noqa: E402
 n = sizes[0]
 pt = np.resize(O.splitmix_bytes(min(n, 64 << 20), 10), n)
 want = pt.copy()
 O.cycle_at(want, O.KEY_PS4, 0)
-M.debug_set_host_tunable("feed_patience_ms", 40)
+PATIENCE_S = 0.04
+M.debug_set_host_tunable("feed_patience_ms", int(PATIENCE_S * 1000))
+gave_up = getattr(M.lib(), "modgpu_shim_feed_gave_up", None)  # (the CPU stand-in counts its kernels that gave up; the real runtime has no such symbol)
+if gave_up is not None:
+    import ctypes
+    gave_up.restype = ctypes.c_ulonglong
 try:
     buf = pt.copy()
     before = M.path_stats()
+    gave_up_before = gave_up() if gave_up else 0
     M.debug_inject_failure_at(M.INJECT_PIECE_MIDDLE, M.STAGE_STALL)
     t0 = time.perf_counter()
     try:
@@ -111,7 +122,10 @@ try:
     except Exception as e:  # noqa: BLE001
         assert strict and "gave up" in str(e), str(e)
     waited = time.perf_counter() - t0
-    assert not M.debug_injection_armed() and 0.15 < waited < 20.0, waited
+    # at least the kernel's patience (it really waited), and nowhere near the stall's own two-minute bound (it really left)
+    assert not M.debug_injection_armed() and PATIENCE_S * 0.9 < waited < 60.0, waited
+    if gave_up:
+        assert gave_up() == gave_up_before + 1
     if not strict:
         after = M.path_stats()
         assert np.array_equal(buf, want) and after["midcall_rescues"] == before["midcall_rescues"] + 1, (before, after)
@@ -121,10 +135,11 @@ try:
     else:
         cycle(buf)
     assert np.array_equal(buf, want) and M.last_launch()["variant"] == 4
+    assert M.last_launch()["source_hash"] == M.feed_kernel_source_hash()
 finally:
     M.debug_set_host_tunable("feed_patience_ms", 10000)
 
-if not strict:
+if not strict and not only_stall:
     n = sizes[0]
     pt = np.resize(O.splitmix_bytes(min(n, 64 << 20), 9), n)
     want = pt.copy()
@@ -161,23 +176,43 @@ if not strict:
     path = os.path.join(d, "midcall_%d.part" % os.getpid())
     pt.tofile(path)
     try:
-        for pinned_dst in (False, True):
-            for piece, stage in ((0, M.STAGE_FILL), (M.INJECT_PIECE_MIDDLE, M.STAGE_SYNC), (M.INJECT_PIECE_LAST, M.STAGE_LAUNCH), (M.INJECT_PIECE_MIDDLE, M.STAGE_AFTER_DRAIN)):
-                if pinned_dst:
-                    pb = M.PinnedBuffer(n)
-                    dst = pb.array
-                else:
-                    dst = np.zeros(n, np.uint8)
-                dst[:] = 0xEE
-                before = M.path_stats()
-                M.debug_inject_failure_at(piece, stage)
-                M.cycle_file_to_host(path, n, M.KEY_PS4, out=dst)
-                after = M.path_stats()
-                assert not M.debug_injection_armed()
-                assert np.array_equal(dst, want), ("file -> host", pinned_dst, piece, stage)
-                assert after["midcall_rescues"] == before["midcall_rescues"] + 1 and after["auto_fallbacks"] == before["auto_fallbacks"]
-                if pinned_dst:
-                    pb.free()
+        # Since round 6 both take the host-fed kernel (one launch per call): into pageable memory through the slots (pread replaces the
+        # copy in), into page-locked memory IN PLACE (the chunks are read to where they belong; `shift` misaligns the destination so
+        # that the < 16 bytes in front of its first 16-byte boundary travel with chunk 0).  file_feed = 0: round 5's launch per chunk.
+        for file_feed in (1, 0):
+            M.debug_set_host_tunable("file_feed", file_feed)
+            for pinned_dst, shift in ((False, 0), (True, 0), (True, 5)):
+                for piece, stage in ((0, M.STAGE_FILL), (M.INJECT_PIECE_MIDDLE, M.STAGE_SYNC), (M.INJECT_PIECE_LAST, M.STAGE_LAUNCH), (M.INJECT_PIECE_MIDDLE, M.STAGE_AFTER_DRAIN),
+                                     (M.INJECT_PIECE_LAST, M.STAGE_DRAIN), (0, M.STAGE_SYNC)) + (((M.INJECT_PIECE_MIDDLE, M.STAGE_STALL),) if file_feed else ()):
+                    if stage == M.STAGE_DRAIN and pinned_dst:
+                        continue  # (nothing is copied out on the in-place routes: the stage does not exist there)
+                    if pinned_dst:
+                        pb = M.PinnedBuffer(n + 16)
+                        pb.array[:] = 0
+                        dst = pb.array[shift:shift + n]
+                    else:
+                        dst = np.zeros(n, np.uint8)
+                    dst[:] = 0xEE
+                    before = M.path_stats()
+                    if stage == M.STAGE_STALL:
+                        M.debug_set_host_tunable("feed_patience_ms", 40)
+                    M.host_trace(True)
+                    M.debug_inject_failure_at(piece, stage)
+                    M.cycle_file_to_host(path, n, M.KEY_PS4, out=dst)
+                    M.host_trace(False)
+                    after = M.path_stats()
+                    M.debug_set_host_tunable("feed_patience_ms", 10000)
+                    ev = M.host_trace_read()
+                    fed = any(e["kind"] == "ready" or (e["kind"] == "launched" and e["pipe"] < 0) for e in ev)
+                    per_chunk = any(e["kind"] == "launched" and e["pipe"] >= 0 for e in ev)
+                    assert not (per_chunk if file_feed else fed), ("wrong route", file_feed, pinned_dst, [e["kind"] for e in ev][:12])
+                    assert not M.debug_injection_armed(), ("the failure never fired", file_feed, pinned_dst, shift, piece, stage)
+                    assert np.array_equal(dst, want), ("file -> host", file_feed, pinned_dst, shift, piece, stage, int(np.flatnonzero(dst != want)[0]))
+                    assert after["midcall_rescues"] == before["midcall_rescues"] + 1 and after["auto_fallbacks"] == before["auto_fallbacks"]
+                    if pinned_dst:
+                        assert np.all(pb.array[:shift] == 0) and np.all(pb.array[shift + n:] == 0)  # guard bytes either side
+                        pb.free()
+        M.debug_set_host_tunable("file_feed", 1)
         # ---- the other two file routes: host -> file (SaveArk's part cipher; the source memory is never modified) and file -> file,
         # to another file and in place (a piece is written only when it is finished, so the unwritten ones are still plaintext)
         out_path = path + ".out"

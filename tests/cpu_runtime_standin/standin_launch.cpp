@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <thread>
 
 #include "../../modulate_amd/csrc/cycle_feed_kernel.h"
@@ -19,12 +20,21 @@ std::atomic<unsigned long long> g_collisions{0}, g_launches[kCycleVariants] = {}
 
 struct Launch { CycleArgs a; int variant; };
 
+// MODGPU_SHIM_SLOW=N (tests): the stand-in "GPU" takes N times as long over every span -- what a loaded box does to it anyway, on
+// purpose: a test that only passes while the stand-in is quick depends on the clock, not on the library.
+const int g_slow = [] {
+    const char *v = std::getenv("MODGPU_SHIM_SLOW");
+    const int x = v ? std::atoi(v) : 1;
+    return x < 1 ? 1 : x;
+}();
 void span(uint8_t *p, uint64_t n, uint32_t state) // state = canonical state of p[0]
 {
+    const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t i = 0; i < n; ++i) {
         p[i] ^= (uint8_t)~state;
         state = lcg::mulmod(state, lcg::A);
     }
+    if (g_slow > 1 && n >= 4096) std::this_thread::sleep_for((std::chrono::steady_clock::now() - t0) * (g_slow - 1));
 }
 
 void run(void *arg)
@@ -109,7 +119,8 @@ void run_feed(void *arg)
         }
         if (gave_up) break;
         const uint64_t pos = c * a->chunk_bytes, len = std::min<uint64_t>(a->chunk_bytes, a->n - pos);
-        uint8_t *slot = a->slot[(c % a->pipes) * 2 + (c / a->pipes) % 2];
+        uint8_t *slot = a->pipes ? a->slot[(c % a->pipes) * 2 + (c / a->pipes) % 2] : a->slot[0] + pos; // pipes == 0: in place, contiguous
+        if (c == 0 && a->pipes == 0 && a->head) span(a->slot[0] - a->head, a->head, a->base_head);
         span(slot, len, lcg::mulmod(a->base, lcg::powmod(lcg::A, pos % lcg::PERIOD)));
         std::atomic_ref<uint32_t>(a->done[c]).store(1u, std::memory_order_release);
     }

@@ -49,7 +49,9 @@ def hooks(lib):
             M.debug_inject_failure_at(0, -1)
             M.debug_set_gpu_node(-2)
             M.debug_set_host_tunable("feed", 1)
+            M.debug_set_host_tunable("file_feed", 1)
             M.debug_set_host_tunable("feed_chunk_bytes", 256 << 10)
+            M.debug_forbid_worker_threads(False)
 
 
 def want(pt, key, off=0):
@@ -221,6 +223,34 @@ def test_host_fed_kernel_route(hooks, lib):
     M.debug_set_host_tunable("feed", 1)
 
 
+def test_no_worker_threads_to_be_had(hooks, lib, tmp_path):
+    """the host-fed routes only work if a call's pipelines run side by side -- their one kernel draws chunks in stream order
+    and waits for whichever pipeline owns the next.  When thread creation fails (a pids / NPROC limit) the caller runs the pipelines
+    itself, one after another; such a call must take the launch-per-chunk schedule instead of parking 32 workgroups on chunks of
+    pipelines that have not started.  Forbidding worker threads: same bytes, no host-fed launch, no pipeline run by a worker; allowed
+    again: the host-fed kernel is back."""
+    pt = O.splitmix_bytes((9 << 20) + 11, 77)
+    path = tmp_path / "part.bin"
+    pt.tofile(path)
+    feeds, tasks = lib.modgpu_shim_feed_launches(), M.host_pool_stats()["pipelines_run_by_workers"]
+    M.debug_forbid_worker_threads(True)
+    try:
+        assert np.array_equal(M.cycle_host(pt.copy(), M.KEY_PS4), want(pt, M.KEY_PS4))
+        assert M.last_launch()["variant"] != 4
+        pb = M.PinnedBuffer(pt.size)
+        M.cycle_file_to_host(str(path), pt.size, M.KEY_PS4, out=pb.array)
+        assert np.array_equal(pb.array, want(pt, M.KEY_PS4)) and M.last_launch()["variant"] != 4
+        assert lib.modgpu_shim_feed_launches() == feeds and M.host_pool_stats()["pipelines_run_by_workers"] == tasks
+        assert lib.modgpu_shim_feed_gave_up() == 0
+    finally:
+        M.debug_forbid_worker_threads(False)
+    assert np.array_equal(M.cycle_host(pt.copy(), M.KEY_PS4), want(pt, M.KEY_PS4)) and M.last_launch()["variant"] == 4
+    M.cycle_file_to_host(str(path), pt.size, M.KEY_PS4, out=pb.array)
+    assert np.array_equal(pb.array, want(pt, M.KEY_PS4)) and M.last_launch()["variant"] == 4
+    pb.free()
+    assert lib.modgpu_shim_feed_launches() == feeds + 2
+
+
 def test_concurrent_callers_share_one_device_and_the_parked_workers(hooks):
     """Round 4: a device's staging context hands SLOTS to calls instead of holding one mutex for a whole call, and its
     pipelines run on parked worker threads instead of threads spawned per call.  Four threads call modgpu_cycle_host on
@@ -383,6 +413,22 @@ def test_gpu_lost_in_the_middle_of_a_call(hooks, tmp_path):
     import sys
     argv = sys.argv
     sys.argv = ["_midcall_child.py", "12,33", "--files", str(tmp_path)]
+    try:
+        with pytest.raises(SystemExit) as e:
+            runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_midcall_child.py"), run_name="__main__")
+        assert e.value.code == 0
+    finally:
+        sys.argv = argv
+        M.debug_inject_failure_at(0, -1)
+
+
+def test_host_goes_away_under_a_waiting_kernel(hooks):
+    """Only the host-stall case of tests/_midcall_child.py: tests/test_sanitizers.py runs THIS one again with the stand-in "GPU" slowed ten
+    times (MODGPU_SHIM_SLOW=10), to show that the case no longer depends on who reaches the stalled chunk first."""
+    import runpy
+    import sys
+    argv = sys.argv
+    sys.argv = ["_midcall_child.py", "12", "--only-stall"]
     try:
         with pytest.raises(SystemExit) as e:
             runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_midcall_child.py"), run_name="__main__")

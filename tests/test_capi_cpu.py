@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(modgpu):
     assert modgpu.active_flavour() == "shipped" and not modgpu.testing_hooks()
     for name in list(modgpu.EXPORTS) + list(modgpu.TESTING_EXPORTS):
         assert getattr(L, name) is not None
-    assert L.modgpu_abi_version() == 7
+    assert L.modgpu_abi_version() == 8
 
     def exported(path):
         out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
@@ -60,6 +60,12 @@ def test_kernel_source_hash_matches_sources(modgpu):
     for f in ("cycle_kernel_impl.h", "cycle_kernel.hip", "cycle_kernel.h", "lcg.h"):
         h.update(open(os.path.join(ROOT, "modulate_amd", "csrc", f), "rb").read())
     assert modgpu.kernel_source_hash() == h.hexdigest()
+    # the host-fed kernel's TU has an identity of its own: modgpu_last_launch reports it for variant 4 and the
+    # roofline_pcie profiles record it
+    h = hashlib.sha256()
+    for f in ("cycle_feed_kernel.hip", "cycle_feed_kernel.h", "cycle_kernel_impl.h", "lcg.h"):
+        h.update(open(os.path.join(ROOT, "modulate_amd", "csrc", f), "rb").read())
+    assert modgpu.feed_kernel_source_hash() == h.hexdigest() != modgpu.kernel_source_hash()
 
 
 def test_state_at_matches_oracle(modgpu, oracle):
@@ -393,8 +399,8 @@ def test_device_alias_needs_a_device(modgpu):
 def test_kernel_codegen_guard_passes_the_tree_and_rejects_a_broken_build():
     """The streaming kernels' keystream is a hand-scheduled assembly block in FIXED registers; the work-queue kernel's ticket
     fetch must stay one plain returning atomic.  Whether the compiler kept to that is visible only in its output, so
-    modulate_amd/csrc/check_isa.py reads the gfx950 assembly -- `make` runs it before it will produce cycle_kernel.o.  Here:
-    the tree's TU passes, and a build with an input of the block pinned into one of its fixed temporaries (round 3's
+    modulate_amd/csrc/check_isa.py reads the gfx950 assembly of BOTH kernel TUs -- `make` runs it before it will produce either
+    object.  Here: the tree's TUs pass, and a build with an input of the block pinned into one of its fixed temporaries (round 3's
     wrong-keystream build) is REJECTED.  hipcc is part of the build container: its absence is a failure, not a skip."""
     hipcc = "/opt/rocm/bin/hipcc"
     assert os.path.exists(hipcc), "hipcc is missing: the code-generation guard cannot run, and that is not acceptable for a build box"
@@ -403,14 +409,85 @@ def test_kernel_codegen_guard_passes_the_tree_and_rejects_a_broken_build():
                            capture_output=True, text=True).stdout.split()
     assert "-amdgpu-atomic-optimizer-strategy=None" in flags, flags
     good = subprocess.run(["make", "-s", "-C", csrc, "isa-check"], capture_output=True, text=True, timeout=900)
-    assert good.returncode == 0 and "check_isa: ok (3 kernels)" in good.stdout, good.stdout[-3000:] + good.stderr[-2000:]
+    assert good.returncode == 0 and "check_isa: ok (4 kernels)" in good.stdout, good.stdout[-3000:] + good.stderr[-2000:]
     broken = subprocess.run(["make", "-s", "-C", csrc, "isa-check-broken"], capture_output=True, text=True, timeout=900)
     assert broken.returncode != 0, "the guard accepted a build whose keystream block reads a register the block overwrites"
     assert "the compiler gave a block operand a fixed temporary" in broken.stdout, broken.stdout[-3000:]
-    # the object file rule depends on the guard: a TU that fails it produces no cycle_kernel.o
+    # the object file rules depend on the guard: a TU that fails it produces neither cycle_kernel.o nor cycle_feed_kernel.o
     mk = open(os.path.join(csrc, "Makefile")).read()
-    rule = mk[mk.index("cycle_kernel.o:"):mk.index("isa-check:")]
-    assert rule.index("check_isa.py cycle_kernel.s") < rule.index("-c cycle_kernel.hip")
+    stamp = mk[mk.index("isa_checked.stamp:"):mk.index("cycle_kernel.o:")]
+    assert "check_isa.py cycle_kernel.s cycle_feed_kernel.s" in stamp
+    for obj in ("cycle_kernel.o:", "cycle_feed_kernel.o:"):
+        assert "isa_checked.stamp" in mk[mk.index(obj):].splitlines()[0], obj
+
+
+def _check_isa():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(ROOT, "modulate_amd", "csrc", "check_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_codegen_guard_sdwa_forwarding_rule():
+    """on gfx940+ a VALU that reads a VGPR directly behind an SDWA write of PART of it (dst_sel BYTE_n) needs a
+    wait state; LLVM's hazard recognizer does not look into inline assembly, and the small shape's and the host-fed kernel's put_byte
+    is one such instruction per asm statement.  Until round 6 only the scheduler's habit of putting a shift between two of them kept
+    that safe; now check_isa.py refuses a TU in which any kernel has such a pair.  The tree passes (previous test); a build whose
+    put_byte is followed at once by a reader of the dword is rejected, in both TUs; and so is the tree's own assembly with the one
+    instruction of margin taken out."""
+    csrc = os.path.join(ROOT, "modulate_amd", "csrc")
+    broken = subprocess.run(["make", "-s", "-C", csrc, "isa-check-broken-sdwa"], capture_output=True, text=True, timeout=900)
+    assert broken.returncode != 0, "the guard accepted a read directly behind an SDWA partial write"
+    out = broken.stdout
+    assert "dst_sel forwarding hazard" in out and "modgpu_cycle_feed_kernel" in out and "modgpu_cycle_kernelILi1ELi256E" in out, out[-3000:]
+    ci = _check_isa()
+    subprocess.check_call(["make", "-s", "-C", csrc, "cycle_feed_kernel.s"])
+    asm = open(os.path.join(csrc, "cycle_feed_kernel.s")).read()
+    assert ci.check(asm) == []
+    lines = asm.splitlines()
+    sd = [i for i, ln in enumerate(lines) if "v_add_u32_sdwa" in ln and "UNUSED_PRESERVE" in ln]
+    hit = 0
+    for a, b in zip(sd, sd[1:]):  # two consecutive put_byte's of ONE dword: drop what the scheduler put between them
+        if lines[a].split()[1] == lines[b].split()[1]:
+            twin = "\n".join(lines[:a + 1] + lines[b:])
+            assert any("dst_sel forwarding hazard" in f for f in ci.check(twin)), (lines[a], lines[b])
+            hit += 1
+    assert hit >= 1  # (if the scheduler ever stops interleaving, the tree itself fails the guard -- which is the point)
+
+
+def test_codegen_guard_barriers_need_the_whole_wave():
+    """VERDICT r5 #2(ii) / ADVICE: the host-fed kernel's lab form hung a workgroup -- lanes 1..63 of one wave went round the trip
+    loop's back edge without lane 0 and met the barrier twice per trip.  It was fixed by source shape; check_isa.py now follows the
+    COMPILED control flow of every kernel with a stack of saved EXEC masks and refuses a build in which an s_barrier can be reached
+    with part of the wave masked off.  Here: the tree's four kernels pass that rule (8 barriers between them), and the host-fed
+    kernel's assembly with the EXEC restore in front of a barrier taken out -- the wave arrives with only thread 0's region's mask --
+    is rejected; so are nt stores and a third barrier."""
+    import re
+    csrc = os.path.join(ROOT, "modulate_amd", "csrc")
+    ci = _check_isa()
+    subprocess.check_call(["make", "-s", "-C", csrc, "cycle_kernel.s", "cycle_feed_kernel.s"])
+    main = open(os.path.join(csrc, "cycle_kernel.s")).read()
+    feed = open(os.path.join(csrc, "cycle_feed_kernel.s")).read()
+    for asm in (main, feed):
+        for name, fn in ci.kernel_texts(asm).items():
+            assert ci.barriers_at_full_exec(name, fn) == [], name
+    assert sum(fn.count("s_barrier") for asm in (main, feed) for fn in ci.kernel_texts(asm).values()) >= 8
+    # every exec restore that directly precedes a barrier, taken out in turn
+    lines = feed.splitlines()
+    twins = 0
+    for i, ln in enumerate(lines):
+        if ln.strip() == "s_barrier":
+            back = [k for k in range(max(0, i - 4), i) if lines[k].strip().startswith("s_or_b64 exec, exec,")]
+            if back:
+                twin = "\n".join(lines[:back[-1]] + lines[back[-1] + 1:])
+                assert any("part of the wave masked off" in f for f in ci.check(twin)), lines[back[-1]]
+                twins += 1
+    assert twins == 2
+    assert any("not `sc1` without nt" in f for f in ci.check(re.sub(r"(buffer_store_dwordx4 [^\n]*) sc1", r"\1 nt sc1", feed)))
+    assert any("s_barrier, expected 2" in f for f in ci.check(feed.replace("\ts_barrier\n", "\ts_barrier\n\ts_barrier\n", 1)))
+    md = ci.metadata(feed, next(iter(ci.kernel_bodies(feed))))
+    assert md["vgpr_count"] <= 64 and md["vgpr_spill_count"] == 0 and md["sgpr_spill_count"] == 0 and md["private_segment_fixed_size"] == 0
 
 
 def test_lab_kernel_at_the_products_settings_is_the_products_loop():
@@ -515,7 +592,7 @@ def test_environment_of_the_shipped_library_is_what_the_header_lists():
                                  "MODGPU_NUMA", "MODGPU_HELPER_BELOW_MHZ", "MODGPU_HOST_PIPES", "MODGPU_HOST_CHUNK_MB"}, (sorted(shipped), sorted(listed))
     testing = names(os.path.join(ROOT, "modulate_amd", "libmodgpu_testing.so"))
     assert testing - shipped == {"MODGPU_HOST_ZEROCOPY_KB", "MODGPU_HOST_RING", "MODGPU_HOST_SPLIT", "MODGPU_HOST_CHUNK_MIN_MB", "MODGPU_HOST_RAMP_KB", "MODGPU_HOST_LANES",
-                                  "MODGPU_HOST_NTCOPY", "MODGPU_HOST_FILE_SCHED", "MODGPU_HOST_FEED", "MODGPU_HOST_FEED_CHUNK_KB", "MODGPU_HOST_SPREAD", "MODGPU_HOST_CGROUP"}, sorted(testing - shipped)
+                                  "MODGPU_HOST_NTCOPY", "MODGPU_HOST_FILE_SCHED", "MODGPU_HOST_FILE_FEED", "MODGPU_HOST_FEED", "MODGPU_HOST_FEED_CHUNK_KB", "MODGPU_HOST_SPREAD", "MODGPU_HOST_CGROUP"}, sorted(testing - shipped)
     code = ("import json, modulate_amd as M; a = [M.host_tunables(), M.host_chunking()]; M.use_testing_flavour(); "
             "print('T', json.dumps([a, [M.host_tunables(), M.host_chunking()]]))")
     e = {k: v for k, v in os.environ.items() if not k.startswith("MODGPU_HOST_")}

@@ -253,6 +253,81 @@ def test_host_fed_kernel_route(gpu_t, oracle):
         gpu.debug_set_host_tunable("feed_chunk_bytes", 256 << 10)
 
 
+def test_file_to_memory_takes_the_host_fed_kernel(gpu_t, oracle, tmp_path):
+    """VERDICT r5 #3 (LoadArkData's part cipher, Modulate/CArk.cpp:741-755): a part FILE that ends in memory is cycled by ONE host-fed
+    launch per call.  Into pageable memory pread replaces the copy into the slot; into page-locked memory the chunks are read to where
+    they belong and the kernel cycles them IN PLACE -- counted from the destination's first 16-byte boundary, the bytes in front of it
+    travel with chunk 0, so every misalignment 0..15 is a case.  Ragged sizes (a short last piece, a tail that is no whole word, a call
+    of one or two chunks), file windows with their own stream offset, 32 KiB .. 1 MiB chunks; whole buffers incl. guard bytes; exactly
+    one launch per call, and it is the host-fed kernel with its TU's own source hash; file_feed = 0 gives round 5's launch per chunk
+    and the same bytes."""
+    gpu = gpu_t
+    sizes = [(1 << 20) + 1, (1 << 20) + 32768 + 17, (2 << 20) + 4097, (3 << 20) - 1, (9 << 20) + 15, (33 << 20) + 32767]
+    big = oracle.splitmix_bytes(max(sizes) + 70_001, 606)
+    path = tmp_path / "part.ark"
+    big.tofile(path)
+    pb = gpu.PinnedBuffer(max(sizes) + 64)
+    try:
+        for chunk in (256 << 10, 32 << 10, 1 << 20):
+            gpu.debug_set_host_tunable("feed_chunk_bytes", chunk)
+            for k, n in enumerate(sizes):
+                file_off, off = (0, 0) if k % 2 == 0 else (70_001, (1 << 40) + 3 + k)
+                want = big[file_off:file_off + n].copy()
+                oracle.cycle_at(want, 0xC64EED30, off)
+                # -> pageable memory
+                out = np.full(n + 32, 0xEE, np.uint8)
+                before = gpu.path_stats()["gpu_launches"]
+                gpu.cycle_file_to_host(path, n, 0xC64EED30, file_off=file_off, stream_off=off, out=out[9:9 + n])
+                ll = gpu.last_launch()
+                assert ll["kernel"] == "modgpu_cycle_feed_kernel" and ll["variant"] == 4 and ll["source_hash"] == gpu.feed_kernel_source_hash(), ll
+                assert gpu.path_stats()["gpu_launches"] == before + 1
+                assert np.array_equal(out[9:9 + n], want) and np.all(out[:9] == 0xEE) and np.all(out[9 + n:] == 0xEE), (chunk, n, "pageable")
+                # -> page-locked memory, in place, at every misalignment for the smallest size and a few for the others
+                for shift in (range(16) if k == 0 and chunk == (256 << 10) else (0, 5 + k, 15)):
+                    pb.array[:] = 0xEE
+                    before = gpu.path_stats()["gpu_launches"]
+                    gpu.cycle_file_to_host(path, n, 0xC64EED30, file_off=file_off, stream_off=off, out=pb.array[shift:shift + n])
+                    ll = gpu.last_launch()
+                    assert ll["variant"] == 4 and gpu.path_stats()["gpu_launches"] == before + 1, ll
+                    got = pb.array[shift:shift + n]
+                    assert np.array_equal(got, want), (chunk, n, shift, int(np.flatnonzero(got != want)[0]))
+                    assert np.all(pb.array[:shift] == 0xEE) and np.all(pb.array[shift + n:shift + n + 32] == 0xEE), (chunk, n, shift, "guard bytes")
+        gpu.debug_set_host_tunable("file_feed", 0)
+        n = sizes[4]
+        want = oracle.cycle(big[:n].copy(), 0xC64EED30)
+        assert np.array_equal(gpu.cycle_file_to_host(path, n, 0xC64EED30), want) and "feed" not in gpu.last_launch()["kernel"]
+        gpu.cycle_file_to_host(path, n, 0xC64EED30, out=pb.array[3:3 + n])
+        assert np.array_equal(pb.array[3:3 + n], want) and "feed" not in gpu.last_launch()["kernel"]
+    finally:
+        gpu.debug_set_host_tunable("file_feed", 1)
+        gpu.debug_set_host_tunable("feed_chunk_bytes", 256 << 10)
+        pb.free()
+
+
+def test_modgpu_prepare_for_callers_with_their_own_device_memory(gpu):
+    """modgpu_alloc prepares the device and modgpu_h2d wakes the shader engines -- for callers who upload through
+    THEM.  A caller with its own hipMalloc / hipMemcpy gets the same by name: modgpu_prepare(device), ABI 8.  Fresh processes (that is
+    the point: a process's first launch), own upload of a 411 MB part after 1.5 s of idleness, ONE launch with its own pair of HIP
+    events: with modgpu_prepare it is within 10 % of the size's steady rate (median of three processes; events from an idle queue
+    include the dispatch latency, profiles/r05_first_launch.txt run F); without it the same launch pays the code object and the ring."""
+    import json
+    import sys
+    tool = os.path.join(ROOT, "tools", "first_launch_own_upload.py")
+
+    def run(*flags):
+        r = subprocess.run([sys.executable, tool, *flags], capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    with_prepare = [run("--prepare") for _ in range(3)]
+    without = run()
+    assert all(x["involution_ok"] and x["kernel"].startswith("modgpu_cycle_queue_kernel") for x in with_prepare + [without])
+    ratios = sorted(x["first_over_steady"] for x in with_prepare)
+    print("first launch / steady, own upload + modgpu_prepare:", ratios, " without:", without["first_over_steady"], without["first_launch"])
+    assert ratios[1] <= 1.10, (with_prepare, without)
+    assert without["first_over_steady"] > ratios[1]  # (what the call is for: ~10 ms of code-object load otherwise land in this launch)
+    assert gpu.lib().modgpu_abi_version() == 8
+
+
 def test_parts_sharding_host(gpu, oracle):
     sizes = [0, 1, 4096, 1_000_003, (8 << 20) + 5, 77]
     parts = [oracle.splitmix_bytes(s, 100 + i) for i, s in enumerate(sizes)]

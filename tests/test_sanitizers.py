@@ -33,7 +33,7 @@ def test_host_logic_under_asan_ubsan():
     assert "passed" in r.stdout
 
 
-def _san_lib_cases(preload, lib, extra_env):
+def _san_lib_cases(preload, lib, extra_env, select=(), expect="15 passed"):
     from oracle import oracle as O
     O.build(ref=False)  # here, not in the child: the compiler must not run under a preloaded sanitizer runtime
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "modulate_amd", "csrc"), "sanitize-lib"])
@@ -42,9 +42,9 @@ def _san_lib_cases(preload, lib, extra_env):
     # (1 MiB slots and a 256 KiB ramp: buffers of 12 MiB and up take the ramped plan -- small first / last chunk per pipeline -- on few MiB)
     for k in ("MODGPU_HOST_PIPES", "MODGPU_HOST_ZEROCOPY_KB", "MODGPU_DEVICE_ALIAS", "MODGPU_HOST_SPLIT", "MODGPU_HOST_CHUNK_MIN_MB", "MODGPU_HOST_LANES"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "san_lib_cases.py"), "-x", "-q", "-p", "no:cacheprovider"],
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "san_lib_cases.py"), "-x", "-q", "-p", "no:cacheprovider"] + list(select),
                        env=env, capture_output=True, text=True, cwd=ROOT, timeout=1500)
-    assert r.returncode == 0 and "13 passed" in r.stdout, r.stdout[-4000:] + r.stderr[-4000:]
+    assert r.returncode == 0 and expect in r.stdout, r.stdout[-4000:] + r.stderr[-4000:]
 
 
 def test_library_host_code_under_asan_ubsan():
@@ -65,5 +65,18 @@ def test_library_host_code_under_tsan():
     tsan = _runtime("libtsan.so")
     if not tsan:
         pytest.skip("gcc ThreadSanitizer runtime not installed")
-    _san_lib_cases(tsan, "libmodgpu_tsan.so",
-                   {"TSAN_OPTIONS": f"halt_on_error=1 second_deadlock_stack=1 suppressions={os.path.join(ROOT, 'tests', 'tsan.supp')}"})
+    opts = {"TSAN_OPTIONS": f"halt_on_error=1 second_deadlock_stack=1 suppressions={os.path.join(ROOT, 'tests', 'tsan.supp')}"}
+    _san_lib_cases(tsan, "libmodgpu_tsan.so", opts)
+
+
+def test_midcall_cases_do_not_depend_on_who_arrives_first():
+    """round 5's host-stall case slept for 4 x the kernel's patience from the moment the PIPELINE reached the
+    chunk and demanded a rescue; under TSan on a loaded box the stand-in kernel reached the chunk when the stall was nearly over,
+    waited less than its patience and finished the call normally -- a red test, one run in three, with a correct library.  The
+    stall now lasts until the kernel has given up, whoever arrives first.  Proof: that case (and the host-fed route's parity cases) under TSan with the stand-in
+    "GPU" slowed TEN times (MODGPU_SHIM_SLOW: every span it cycles takes ten times as long, so it is always the late one)."""
+    tsan = _runtime("libtsan.so")
+    if not tsan:
+        pytest.skip("gcc ThreadSanitizer runtime not installed")
+    opts = {"TSAN_OPTIONS": f"halt_on_error=1 second_deadlock_stack=1 suppressions={os.path.join(ROOT, 'tests', 'tsan.supp')}", "MODGPU_SHIM_SLOW": "10"}
+    _san_lib_cases(tsan, "libmodgpu_tsan.so", opts, select=("-k", "host_goes_away_under_a_waiting_kernel or host_fed_kernel_route"), expect="2 passed")

@@ -11,8 +11,8 @@ rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 # the default bench command (N=1, 20 steps, 3 warmup); the CPU-baseline leg is skipped under the
 # counter passes only (it adds 12 s of host work and no kernels)
-BENCH_TRACE="python3 bench.py"
-BENCH="python3 bench.py --no-cpu-baseline"
+BENCH_TRACE="python3 bench.py --no-own-upload-probe"
+BENCH="python3 bench.py --no-cpu-baseline --no-own-upload-probe"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH_TRACE > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/bench_write.log 2>&1
