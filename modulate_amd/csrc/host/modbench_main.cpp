@@ -15,7 +15,7 @@
 //       when the slots were there, when each pipeline started, and per pipeline what its time went into -- filling slots
 //       (memcpy in), waiting for kernels, draining slots (memcpy out); full event list for the 64 MiB call.  Then two
 //       callers at once on one GPU (64 MiB each) against one caller alone.
-//   modbench --route pinned|staged --mib N [--reps R] [--socket near|far]
+//   modbench --route pinned|staged|file_pageable|file_pinned --mib N [--reps R] [--socket near|far] [--dir D]
 //       R calls of modgpu_cycle_host over ONE buffer of N MiB -- page-locked (modgpu_host_alloc: cycled in place by one kernel
 //       across PCIe) or pageable (the staged route) -- with the host-side timeline on for the whole run.  Prints every call's wall
 //       time and, one line each, every kernel launch the library made (thread id, call, pipeline, piece, bytes): run under
@@ -377,6 +377,7 @@ int HostTrace()
 }
 
 // ---- --route: one host-buffer route, R calls, every launch listed (to be joined with a rocprofv3 kernel trace) -------------------
+std::string gRouteDir = "/dev/shm"; // --dir D: where the file routes' part file is put
 uint64_t gRouteOffset = 4; // --offset K: the buffer starts K bytes behind a page boundary (the reference's callers pass buf + 4)
 std::string gRouteSocket;  // --socket near|far: this thread (and so the pages it touches) on the GPU's NUMA node / on another one, before anything
                            // is allocated -- a profile that does not depend on where the scheduler happened to start the process
@@ -412,7 +413,9 @@ int Route( const std::string& kind, uint64_t mib, int reps )
     if( modgpu_device_count() < 1 ) { std::printf( "no HIP device\n" ); return 1; }
     if( !gRouteSocket.empty() ) BindToSocket( gRouteSocket );
     const uint64_t n = mib << 20;
-    const bool pinned = kind == "pinned";
+    // file_pageable / file_pinned: the source is a part file on tmpfs (modgpu_cycle_file_to_host: LoadArkData's part cipher), the destination this buffer
+    const bool fromFile = kind == "file_pageable" || kind == "file_pinned";
+    const bool pinned = kind == "pinned" || kind == "file_pinned";
     void* mem = nullptr;
     std::vector< unsigned char > pageable;
     if( pinned ) TRY( modgpu_host_alloc( &mem, n + 64 ) );
@@ -433,16 +436,32 @@ int Route( const std::string& kind, uint64_t mib, int reps )
         (void)::syscall( SYS_get_mempolicy, &pageNode, nullptr, 0, buf + n / 2, 3 /* MPOL_F_NODE | MPOL_F_ADDR */ );
         std::printf( "placement: calling thread on cpu %u of NUMA node %u; the buffer's middle page on node %d; the GPU hangs off node %d\n", cpu, node, pageNode, modgpu_device_numa_node( 0 ) );
     }
+    std::printf( "hashes kernel %s feed %s\n", modgpu_kernel_source_hash(), modgpu_feed_kernel_source_hash() );
+    std::string path;
+    if( fromFile )
+    {
+        path = gRouteDir + "/modbench_route_" + std::to_string( ::getpid() ) + ".part";
+        std::FILE* f = std::fopen( path.c_str(), "wb" );
+        if( !f || std::fwrite( buf, 1, n, f ) != n ) { std::printf( "cannot write %s\n", path.c_str() ); return 1; }
+        std::fclose( f );
+    }
+    auto once = [ & ]() -> int { return fromFile ? modgpu_cycle_file_to_host( path.c_str(), 0, buf, n, kKey, 0, 0 ) : modgpu_cycle_host( buf, n, kKey, 0, 0 ); };
     modgpu_host_trace( 1 ); // from the first call on: the launch list below must hold EVERY launch the profiler sees
-    for( int i = 0; i < 2; ++i ) TRY( modgpu_cycle_host( buf, n, kKey, 0, 0 ) ); // slots, workers, page faults
+    for( int i = 0; i < 2; ++i ) TRY( once() ); // slots, workers, page faults
     std::vector< double > walls;
     for( int r = 0; r < reps; ++r )
     {
         const double t0 = Now();
-        TRY( modgpu_cycle_host( buf, n, kKey, 0, 0 ) );
+        TRY( once() );
         walls.push_back( Now() - t0 );
     }
     modgpu_host_trace( 0 );
+    if( fromFile )
+    { // every call gave the same ciphertext; one more pass over it in memory must give the file's bytes back
+        ::unlink( path.c_str() );
+        TRY( modgpu_cycle_host( buf, n, kKey, 0, 0 ) );
+        reps = 0; // (the restore check below: "an even number of passes")
+    }
     std::vector< double > sorted = walls;
     std::sort( sorted.begin(), sorted.end() );
     std::printf( "calls (after 2 untimed): best %.3f ms = %.2f GB/s, median %.3f ms = %.2f GB/s of payload (each byte crosses the link twice)\n", sorted.front() * 1e3,
@@ -719,6 +738,7 @@ int main( int argc, char** argv )
         else if( a == "--mib" ) routeMib = std::strtoull( next(), nullptr, 0 );
         else if( a == "--offset" ) gRouteOffset = std::strtoull( next(), nullptr, 0 ) & 4095;
         else if( a == "--socket" ) gRouteSocket = next();
+        else if( a == "--dir" ) gRouteDir = next();
         else if( a == "--reps" ) routeReps = std::max( 1, std::atoi( next() ) );
         else if( a == "--alloc" ) { mode = "alloc"; partBytes = 3291444381ull; nParts = 8; }
         else if( a == "--numa" ) { mode = "numa"; partBytes = 1ull << 30; }
@@ -727,7 +747,7 @@ int main( int argc, char** argv )
         else positional.push_back( argv[ i ] );
     }
     if( mode == "hostcall" ) return trace ? HostTrace() : HostCall();
-    if( mode == "route" ) return route == "pinned" || route == "staged" ? Route( route, routeMib, routeReps ) : 1;
+    if( mode == "route" ) return route == "pinned" || route == "staged" || route == "file_pageable" || route == "file_pinned" ? Route( route, routeMib, routeReps ) : 1;
     if( modgpu_device_count() < 1 ) { std::printf( "no HIP device\n" ); return 1; }
     if( mode == "parts" ) return nParts > 0 ? Parts( nParts, devices, partBytes, steps, std::max( warmup, 1 ) ) : 1;
     if( mode == "files" ) return Files( dir, fileSizes );

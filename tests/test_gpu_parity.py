@@ -308,8 +308,11 @@ def test_modgpu_prepare_for_callers_with_their_own_device_memory(gpu):
     """modgpu_alloc prepares the device and modgpu_h2d wakes the shader engines -- for callers who upload through
     THEM.  A caller with its own hipMalloc / hipMemcpy gets the same by name: modgpu_prepare(device), ABI 8.  Fresh processes (that is
     the point: a process's first launch), own upload of a 411 MB part after 1.5 s of idleness, ONE launch with its own pair of HIP
-    events: with modgpu_prepare it is within 10 % of the size's steady rate (median of three processes; events from an idle queue
-    include the dispatch latency, profiles/r05_first_launch.txt run F); without it the same launch pays the code object and the ring."""
+    events -- in the same harness for the three kinds of caller (median of three processes each): own upload + modgpu_prepare is
+    as good as uploading through the library's helpers (within 10 %), both are within 20 % of the size's STEADY rate (measured:
+    1.10-1.15 -- an event pair around a launch from an idle queue also holds the host's planning and packet write, ~12 us of a
+    0.126 ms launch: profiles/r05_first_launch.txt run F has the dispatch itself at 0.127), and without modgpu_prepare the same launch
+    pays the code object and the ring (measured: 11.6 ms, 92 x)."""
     import json
     import sys
     tool = os.path.join(ROOT, "tools", "first_launch_own_upload.py")
@@ -319,12 +322,16 @@ def test_modgpu_prepare_for_callers_with_their_own_device_memory(gpu):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         return json.loads(r.stdout.strip().splitlines()[-1])
     with_prepare = [run("--prepare") for _ in range(3)]
+    via_library = [run("--library-upload") for _ in range(3)]
     without = run()
-    assert all(x["involution_ok"] and x["kernel"].startswith("modgpu_cycle_queue_kernel") for x in with_prepare + [without])
-    ratios = sorted(x["first_over_steady"] for x in with_prepare)
-    print("first launch / steady, own upload + modgpu_prepare:", ratios, " without:", without["first_over_steady"], without["first_launch"])
-    assert ratios[1] <= 1.10, (with_prepare, without)
-    assert without["first_over_steady"] > ratios[1]  # (what the call is for: ~10 ms of code-object load otherwise land in this launch)
+    assert all(x["involution_ok"] and x["kernel"].startswith("modgpu_cycle_queue_kernel") for x in with_prepare + via_library + [without])
+    own = sorted(x["first_over_steady"] for x in with_prepare)[1]
+    lib = sorted(x["first_over_steady"] for x in via_library)[1]
+    print("first launch / steady: own upload + modgpu_prepare", [x["first_over_steady"] for x in with_prepare], " via the library's helpers",
+          [x["first_over_steady"] for x in via_library], " own upload alone:", without["first_over_steady"], without["first_launch"])
+    assert own <= 1.20 and lib <= 1.20, (with_prepare, via_library)
+    assert own <= 1.10 * lib, (own, lib)
+    assert without["first_over_steady"] > 2.0 * own  # (what the call is for)
     assert gpu.lib().modgpu_abi_version() == 8
 
 

@@ -2,7 +2,11 @@
 """tools/summarize_pcie_trace.py -- joins `modbench --route ...`'s list of launches with the rocprofv3 kernel trace of the same run.
 
     rocprofv3 --kernel-trace --stats --output-format csv -d DIR -- modulate_amd/bin/modbench --route staged --mib 64 > LOG
-    python3 tools/summarize_pcie_trace.py LOG DIR [--link-gbps 50.4] > summary.json
+    python3 tools/summarize_pcie_trace.py LOG DIR [--ceilings CEILING_LOG] > summary.json
+
+CEILING_LOG: the output of tools/ubench_pcie_ceiling from the SAME run on the same box.  `roofline_pcie` is priced against figures the
+code under test did not produce: the link on paper (gen 5 x16: 64 GB/s per direction), the DMA engines one way and both
+ways at once -- and, for reference only, what one kernel of the small shape does in place across the link.
 
 The library's host trace names the OS thread that made every launch, rocprofv3's kernel trace names the launching thread of every
 dispatch; a thread's launches and its dispatches are in the same order, which gives every dispatch its bytes, call and pipeline.
@@ -18,12 +22,24 @@ import statistics as st
 import sys
 
 
+def read_ceilings(path):
+    for line in open(path):
+        if line.startswith("CEILING "):
+            return json.loads(line[len("CEILING "):])
+    raise SystemExit(f"{path}: no CEILING line (tools/ubench_pcie_ceiling)")
+
+
+HASHES = {}
+
+
 def read_log(path):
     launches, walls, head, begins, ends = [], {}, None, {}, {}
     for line in open(path):
         w = line.split()
         if not w:
             continue
+        if w[0] == "hashes" and len(w) >= 5:
+            HASHES.update({"kernel_source_hash": w[2], "feed_kernel_source_hash": w[4]})
         if w[0] == "route":
             head = line.strip()
         elif w[0] == "launch":
@@ -67,7 +83,8 @@ def union_ns(iv):
 
 def main():
     log, d = sys.argv[1], sys.argv[2]
-    link = float(sys.argv[sys.argv.index("--link-gbps") + 1]) if "--link-gbps" in sys.argv else 50.4
+    ceil = read_ceilings(sys.argv[sys.argv.index("--ceilings") + 1]) if "--ceilings" in sys.argv else None
+    link = float(ceil["peak_link"]) if ceil else 64.0  # gen 5 x16 per direction, on paper
     head, launches, walls, begins, ends = read_log(log)
     rows = read_trace(d)
     by_tid_l, by_tid_k = {}, {}
@@ -82,7 +99,7 @@ def main():
             unmatched += abs(len(ks) - len(ls))
         for l, k in zip(ls, ks):
             joined.append({**l, **{"start": k["start"], "end": k["end"], "queue": k["queue"], "stream": k["stream"], "kernel": k["kernel"], "grid": k["grid"], "wg": k["wg"]}})
-    out = {"run": head, "launches_listed": len(launches), "dispatches_traced": len(rows), "unmatched": unmatched, "link_GBps_assumed_per_direction": link}
+    out = {"run": head, "launches_listed": len(launches), "dispatches_traced": len(rows), "unmatched": unmatched, "link_GBps_per_direction_on_paper": link, **HASHES}
     calls = sorted({j["call"] for j in joined})
     per_call = []
     for c in calls:
@@ -137,12 +154,22 @@ def main():
     out["per_kernel_by_bytes"] = [
         {"bytes": b, "n": len(v), "median_us": round(st.median(v), 1), "min_us": round(min(v), 1), "max_us": round(max(v), 1),
          "payload_GBps_at_median": round(b / st.median(v) / 1e3, 2), "link_GBps_each_way_at_median": round(b / st.median(v) / 1e3, 2),
-         "frac_of_link_at_median": round(b / st.median(v) / 1e3 / link, 3)}
+         "frac_of_link_on_paper_at_median": round(b / st.median(v) / 1e3 / link, 3)}
         for b, v in sorted(by_size.items())]
     best = max(timed, key=lambda p: p["payload_GBps_over_wall"]) if timed else None
     if best:
-        out["roofline_pcie"] = {"bound": "pcie", "achieved": st.median(p["payload_GBps_over_wall"] for p in timed), "peak": link, "unit": "GB/s of payload (= GB/s in each direction of the link)",
-                                "frac": round(st.median(p["payload_GBps_over_wall"] for p in timed) / link, 4), "best_call": best["payload_GBps_over_wall"]}
+        achieved = st.median(p["payload_GBps_over_wall"] for p in timed)
+        r = {"bound": "pcie", "achieved": achieved, "unit": "GB/s of payload (= GB/s in each direction of the link)", "best_call": best["payload_GBps_over_wall"],
+             "peak": link, "peak_is": "PCIe gen 5 x16 per direction on paper", "frac": round(achieved / link, 4), "peak_link": link, "frac_of_link": round(achieved / link, 4)}
+        if ceil:
+            one_way = min(ceil["dma_h2d"], ceil["dma_d2h"])
+            r.update({"dma_one_way": one_way, "dma_h2d": ceil["dma_h2d"], "dma_d2h": ceil["dma_d2h"], "dma_duplex": ceil["dma_duplex_per_direction"],
+                      "frac_of_dma_one_way": round(achieved / one_way, 4), "frac_of_dma_duplex": round(achieved / ceil["dma_duplex_per_direction"], 4),
+                      "reference_only_one_kernel_in_place": ceil.get("product_pinned_route_in_place"),
+                      "ceilings_from": "tools/ubench_pcie_ceiling, same run: DMA engines (hipMemcpyAsync, 16 MiB pieces) on %d MiB of page-locked memory" % ceil["MiB"]})
+        r["dispatches_per_timed_call"] = round(st.median(p["kernels"] for p in timed), 1)
+        r.update(HASHES)
+        out["roofline_pcie"] = r
     json.dump(out, sys.stdout, indent=1)
     print()
 
