@@ -169,7 +169,7 @@ void modgpu_debug_set_pcie_grid(uint32_t cap);
 
 /* How modgpu_cycle_host treats a pinned caller buffer: 0 = library default (= 2), 1 = DMA ring
  * (H2D -> kernel in HBM -> D2H straight from / to the caller's pages), 2 = one kernel over PCIe on
- * the pages themselves.  Both give the same bytes; tools/sweep_pinned.py times them. */
+ * the pages themselves.  Both give the same bytes; tools/archive/sweep_pinned.py times them. */
 void modgpu_debug_set_pinned_mode(int mode);
 
 /* How a staged chunk (pageable memory or a file, copied into a pinned slot) is cycled: 0 = library

@@ -22,7 +22,7 @@ For EVERY kernel of either TU, whatever its arithmetic (round 6):
   * every s_barrier is reached with the EXEC mask the wave had when it entered the kernel: the kernel's control flow is
     followed with a stack of the masks saved by s_*_saveexec / narrowed by s_andn2 exec, and the stack must be EMPTY at a
     barrier on every path.  (The host-fed kernel's lab form hung a workgroup because lanes 1..63 of one wave went round the
-    trip loop's back edge without lane 0 and met the barrier a second time; tools/ubench_pcie_persist.hip.)
+    trip loop's back edge without lane 0 and met the barrier a second time; tools/archive/ubench_pcie_persist.hip.)
 The host-fed kernel (cycle_feed_kernel.s) in particular: <= 64 VGPRs, no spills, no scratch, 8 bytes of LDS, exactly two
 s_barrier, data loads nt, data stores sc1 and NOT nt (nt stores across PCIe measured 15-20 % slower), the trip's ticket and ok
 word read into scalar registers (v_readfirstlane) behind the first barrier.

@@ -17,7 +17,7 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 // counting the piece of the trip before, then drawing the next ticket and waiting for its chunk.  (A second thread-0 region
 // behind the trip's last barrier had the compiler send lanes 1..63 of wave 0 round the back edge on their own: that wave then
 // passed the barrier twice per trip, the other waves once, and the workgroup hung -- found in the lab form of this kernel,
-// tools/ubench_pcie_persist.hip.)  Two things keep that from coming back with a compiler's mood: what decides whether a wave
+// tools/archive/ubench_pcie_persist.hip.)  Two things keep that from coming back with a compiler's mood: what decides whether a wave
 // goes round again (the ticket, the ok word) is read out of LDS into SCALAR registers (readfirstlane), so the back edge is a
 // scalar branch that a wave takes whole or not at all; and check_isa.py follows the compiled kernel's control flow and refuses
 // a build in which either s_barrier can be reached with anything but the EXEC mask the wave entered the loop with.

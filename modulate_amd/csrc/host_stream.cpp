@@ -337,13 +337,18 @@ int feed_reserve(Staging &s, int slot)
         }
         s.feed_flags[slot] = h;
     }
-    if (!s.feed_work[slot]) { // zero when a call finds them: cleared here once, and by every call behind itself (feed_leave_clean)
+    if (!s.feed_work[slot]) { // zero when a call finds them: cleared here once, and by every call behind itself
+        // Cleared ON THE STREAM THE KERNEL WILL BE LAUNCHED ON (the slot's own; staging_reserve has made it).  A plain hipMemset goes to the
+        // NULL stream, which this non-blocking stream does not wait for, and it may return before the fill has run: round 6 starts the
+        // worker threads before this point, so the launch now follows within microseconds -- and with eight devices' first calls at once
+        // the kernel ran while the fill was still queued: the ticket counter went back to zero under it, pieces were drawn twice and
+        // chunks marked done early (13 of 25 fresh processes returned wrong bytes; gpurun_out/r06e_diag_many.log).
         uint32_t *w = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w), (kFeedChunksMax + 2) * sizeof(uint32_t)));
-        if (hipMemset(w, 0, (kFeedChunksMax + 2) * sizeof(uint32_t)) != hipSuccess) {
+        if (hipMemsetAsync(w, 0, (kFeedChunksMax + 2) * sizeof(uint32_t), s.stream[slot]) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(w);
-            return fail(MODGPU_ERR_HIP, "hipMemset (host-fed kernel's counters)");
+            return fail(MODGPU_ERR_HIP, "hipMemsetAsync (host-fed kernel's counters)");
         }
         s.feed_work[slot] = w;
     }

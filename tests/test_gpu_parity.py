@@ -1180,6 +1180,20 @@ print("ALIAS_OK", st["gpu_calls"], st["gpu_bytes"])
 """
 
 
+def test_first_host_buffer_calls_of_a_process_on_eight_devices_at_once(gpu):
+    """Round 6 regression.  A staging set's counters for the host-fed kernel (ticket counter, pieces finished per chunk) are made by the
+    first call that leads with a slot -- and were cleared with hipMemset, i.e. on the NULL stream, which the kernel's non-blocking
+    stream does not wait for.  Once the worker threads were started BEFORE that point (round 6) the launch followed within microseconds;
+    with eight devices' first calls at once the kernel ran while the fill was still queued, the ticket counter went back to zero under
+    it, pieces were cycled twice and chunks marked done early: 13 of 25 fresh processes returned wrong bytes, silently.  The fill now
+    goes to the kernel's own stream.  Six fresh processes, each making its first eight host-buffer calls at once on eight aliased
+    devices: bytes exact in all."""
+    e = dict(os.environ, MODGPU_DEVICE_ALIAS="8", MODGPU_REQUIRE_GPU="1")
+    for k in range(6):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_first_call_child.py"), "96"], capture_output=True, text=True, env=e, timeout=600)
+        assert r.returncode == 0 and "FIRST_CALL_OK" in r.stdout, (k, r.stdout[-2000:] + r.stderr[-2000:])
+
+
 def test_eight_workers_on_aliased_devices(gpu):
     """the N-worker sharding code (modgpu_cycle_parts_host, per-device staging contexts)
     executed with 8 workers: 8 logical devices aliased onto this box's GPU.  Parts are independent streams

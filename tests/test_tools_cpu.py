@@ -23,6 +23,7 @@ def test_pcie_trace_join_by_thread_and_order(tmp_path):
     # two calls (call 0 is the untimed warm-up: no wall time), two pipeline threads, pieces of 1 and 4 MiB
     log.write_text("\n".join([
         "route staged  bytes 10485760  reps 1",
+        "hashes kernel ddcc feed ffee",
         "call 1 wall_us 400.0",
         "callbegin 0 t_us 0.0", "launch tid 101 call 0 pipe 0 piece 0 bytes 1048576 t_us 10.0", "launch tid 102 call 0 pipe 1 piece 1 bytes 4194304 t_us 12.0", "callend 0 t_us 300.0",
         "callbegin 1 t_us 1000.0", "launch tid 101 call 1 pipe 0 piece 0 bytes 1048576 t_us 1010.0", "launch tid 102 call 1 pipe 1 piece 1 bytes 4194304 t_us 1012.0",
@@ -34,7 +35,11 @@ def test_pcie_trace_join_by_thread_and_order(tmp_path):
         '"KERNEL_DISPATCH","Agent 2",1,1,101,1,9,"__amd_rocclr_fillBufferAligned",1,1,2,0,0,8,0,48,256,1,1,1024,1,1',
         row(1, 101, 2, 5000 * us, 5040 * us), row(2, 102, 3, 5010 * us, 5110 * us),                      # call 0
         row(1, 101, 4, 9000 * us, 9050 * us), row(2, 102, 5, 9020 * us, 9220 * us), row(1, 101, 6, 9100 * us, 9300 * us), ""]))  # call 1
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_pcie_trace.py"), str(log), str(tmp_path / "prof"), "--link-gbps", "50"],
+    # what tools/ubench_pcie_ceiling prints last, from the same run: the figures the roofline is priced against
+    ceil = tmp_path / "ceiling.txt"
+    ceil.write_text('== table\nCEILING {"MiB": 1024, "peak_link": 64.0, "dma_h2d": 55.0, "dma_d2h": 56.0, "dma_duplex_per_direction": 47.0, '
+                    '"product_pinned_route_in_place": 50.4, "kernel_source_hash": "aa", "feed_kernel_source_hash": "bb"}\n')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_pcie_trace.py"), str(log), str(tmp_path / "prof"), "--ceilings", str(ceil)],
                        capture_output=True, text=True, check=True)
     out = json.loads(r.stdout)
     assert out["launches_listed"] == 5 and out["dispatches_traced"] == 5 and out["unmatched"] == 0
@@ -47,8 +52,14 @@ def test_pcie_trace_join_by_thread_and_order(tmp_path):
     by = {k["bytes"]: k for k in out["per_kernel_by_bytes"]}   # timed calls only: call 1
     assert by[1 << 20]["n"] == 1 and by[1 << 20]["median_us"] == 50.0 and by[4 << 20]["n"] == 2 and by[4 << 20]["median_us"] == 200.0
     assert abs(by[4 << 20]["payload_GBps_at_median"] - (4 << 20) / 200e-6 / 1e9) < 0.01
-    assert out["roofline_pcie"]["bound"] == "pcie" and out["roofline_pcie"]["peak"] == 50.0
-    assert abs(out["roofline_pcie"]["achieved"] - (9 << 20) / 400e-6 / 1e9) < 0.01
+    # the peak is the link on paper, with the DMA engines' figures of the same run beside it -- nothing the library's own kernel produced
+    rf = out["roofline_pcie"]
+    ach = (9 << 20) / 400e-6 / 1e9
+    assert rf["bound"] == "pcie" and rf["peak"] == rf["peak_link"] == 64.0 and abs(rf["achieved"] - ach) < 0.01
+    assert abs(rf["frac_of_link"] - ach / 64.0) < 1e-3 and rf["dma_one_way"] == 55.0 and rf["dma_duplex"] == 47.0
+    assert abs(rf["frac_of_dma_one_way"] - ach / 55.0) < 1e-3 and abs(rf["frac_of_dma_duplex"] - ach / 47.0) < 1e-3
+    assert rf["reference_only_one_kernel_in_place"] == 50.4 and rf["dispatches_per_timed_call"] == 3
+    assert out["feed_kernel_source_hash"] == rf["feed_kernel_source_hash"] == "ffee" and out["kernel_source_hash"] == "ddcc"
 
 
 def test_kernel_trace_summary_by_kernel_and_grid(tmp_path):

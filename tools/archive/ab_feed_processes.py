@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/ab_feed_processes.py [processes=8] [MiB=64] -- is a process's rate on the pageable route a property of the PROCESS (where the scheduler and the
+"""tools/archive/ab_feed_processes.py [processes=8] [MiB=64] -- is a process's rate on the pageable route a property of the PROCESS (where the scheduler and the
 allocator put it) or of the schedule?  Each line is a fresh process that runs the launch-per-chunk schedule and the host-fed kernel interleaved on
 one pageable buffer (testing flavour, 12 calls each) and says where its thread and pages were."""
 import ctypes
@@ -8,7 +8,7 @@ import subprocess
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def child(mib):

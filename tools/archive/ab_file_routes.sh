@@ -1,7 +1,7 @@
 #!/bin/bash
 # NOTE (round 5): MODGPU_HOST_LANES / _RAMP_KB / _SPLIT / _CHUNK_MIN_MB / _FILE_LANES are no longer read by libmodgpu.so (modbench links the
 # shipped library); this script documents how profiles/r04_file_routes.txt was taken and does not reproduce it on a round-5 build.
-# tools/ab_file_routes.sh -- the file routes (bin/modbench --files) under round 3's staging settings and under this round's defaults,
+# tools/archive/ab_file_routes.sh -- the file routes (bin/modbench --files) under round 3's staging settings and under this round's defaults,
 # interleaved three times (tmpfs writes vary by +-30 % between runs of one command): did the new chunking / ramp / lanes cost the
 # file endpoints anything?  Run on the GPU box from the repo root.
 O=gpurun_out/ab_files

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/ab_file_sched.py -- file -> page-locked memory (LoadArkData's part cipher) and page-locked memory -> file (SaveArk's) with the file
+"""tools/archive/ab_file_sched.py -- file -> page-locked memory (LoadArkData's part cipher) and page-locked memory -> file (SaveArk's) with the file
 routes' own schedule against the memory routes' schedule (testing flavour, interleaved, best of the repetitions; tmpfs)."""
 import os
 import sys
@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import modulate_amd as M  # noqa: E402
 
 M.use_testing_flavour()

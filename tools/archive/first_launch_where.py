@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/first_launch_where.py [reps=4] -- what makes a process's first 411 MB launch 8 us slower in bench.py's preamble than in a process that
+"""tools/archive/first_launch_where.py [reps=4] -- what makes a process's first 411 MB launch 8 us slower in bench.py's preamble than in a process that
 owns only a 411 MB part (profiles/r05_first_launch.txt, run E)?  Each line below is a FRESH process (the first launch happens once per process)
 that allocates, uploads as bench.py does (64 MiB tiles from pageable memory), then times ONE 411 MB launch and the next one with HIP events:
 
@@ -19,7 +19,7 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CASES = ("alloc411_up411", "alloc4G_up4G_head", "alloc4G_up411_head", "alloc411_up411x10", "alloc4G_up4G_tail", "alloc4G_up4G_head_idle",
          "alloc4G_up4G_head_onecall", "alloc411_up411x10_onecall", "alloc4G_up4G_head_raw", "alloc4G_up4G_head_rawlast", "alloc4G_up4G_head_sleepfirst")
 if os.environ.get("WHERE_ONLY"):

@@ -4,12 +4,12 @@ on the shipped kernels through the library's testing flavour: each size with the
 (a) cold -- 1 GiB of other data cycled in between, so the buffer is out of the Infinity Cache but the chip is busy and its
 clock settled -- and (b) warm, the same buffer again right away.  Median of `rounds`.
 
-    python tools/handover.py [rounds=9]
+    python tools/archive/handover.py [rounds=9]
 """
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["MODGPU_REQUIRE_GPU"] = "1"
 import numpy as np  # noqa: E402
 import modulate_amd as M  # noqa: E402

@@ -1,4 +1,4 @@
-"""tools/hipcheck.py torch_first|modgpu_first -- shows that a process must use ONE HIP runtime: PyTorch
+"""tools/archive/hipcheck.py torch_first|modgpu_first -- shows that a process must use ONE HIP runtime: PyTorch
 bundles its own libamdhip64.so and libmodgpu.so binds to the same SONAME, so whichever loads first
 serves both (torch first: both work; libmodgpu first: torch then sees no GPU).  bench.py therefore
 imports torch before the product library when it needs RCCL, and never otherwise."""

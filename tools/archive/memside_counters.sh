@@ -1,9 +1,9 @@
 #!/bin/bash
-# tools/memside_counters.sh [bytes] -- run on the GPU box from the repo root.  Memory-side counters of the
+# tools/archive/memside_counters.sh [bytes] -- run on the GPU box from the repo root.  Memory-side counters of the
 # L2 -> fabric interface (TCC_EA*), the L2's own stall counters and the vector L1's pending stalls, for four kernels with
 # the SAME schedule at the same size: read-only, write-only, copy, and the product's cycle kernel (tools/ubench_queue_rw).
 # One rocprofv3 --pmc pass per counter group (TCC has 4 slots per pass on gfx950); never together with a trace option.
-# A pass rocprofv3 refuses is recorded as refused and the script goes on.  tools/summarize_memside.py distils the CSVs.
+# A pass rocprofv3 refuses is recorded as refused and the script goes on.  tools/archive/summarize_memside.py distils the CSVs.
 BYTES=${1:-4294967296}
 OUT=gpurun_out/memside
 rm -rf $OUT; mkdir -p $OUT
@@ -41,5 +41,5 @@ done
 # the same program without the profiler, for the rates the counters belong to
 timeout -k 10 120 tools/ubench_queue_rw $BYTES 200 8 > $OUT/rates.txt 2>&1
 cat $OUT/status.txt $OUT/rates.txt
-python3 tools/summarize_memside.py $OUT > $OUT/summary.log 2>&1 || true
+python3 tools/archive/summarize_memside.py $OUT > $OUT/summary.log 2>&1 || true
 tail -60 $OUT/summary.log

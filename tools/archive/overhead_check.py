@@ -1,7 +1,7 @@
-"""tools/overhead_check.py -- wall-clock minus HIP-event time of modgpu_time_cycle_device (the timed region of
+"""tools/archive/overhead_check.py -- wall-clock minus HIP-event time of modgpu_time_cycle_device (the timed region of
 bench.py): ~15-40 us per call, i.e. bench.py's ms_per_step is kernel time, not host overhead."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import modulate_amd as M
 d = M.DeviceBuffer(1 << 32)

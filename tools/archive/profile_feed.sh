@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/profile_feed.sh -- the pageable host route with the host-fed kernel under rocprofv3 (what `reproduce_r05.sh pcie` does for the staged
+# tools/archive/profile_feed.sh -- the pageable host route with the host-fed kernel under rocprofv3 (what `reproduce_r05.sh pcie` does for the staged
 # rows, after the route changed): modbench --route staged under --kernel-trace, every dispatch joined with the library's launch list.
 # The calling thread is put on the GPU's socket (and once, at 64 MiB, on the other) by modbench itself: nothing may stand between `--` and the program.
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"

@@ -8,7 +8,7 @@ build_tools() {   # on the build box (cross-compiles without a GPU); the binarie
     $HIPCC tools/tune_cycle.hip -o tools/tune_cycle
     $HIPCC tools/ubench_queue_rw.hip -o tools/ubench_queue_rw
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench_d2d.hip -o tools/ubench_d2d
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/ubench_latency.hip -o tools/ubench_latency
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/archive/ubench_latency.hip -o tools/archive/ubench_latency
 }
 case "${1:-help}" in
 build) build_tools ;;
@@ -24,11 +24,11 @@ trace)        # r02_trace_static_schedule.txt, r02_trace_queue_schedule.txt
 ceilings)     # r02_ubench_queue_rw.txt, r02_ubench_d2d.txt, r02_ubench_latency.txt
     for g in 200 256; do tools/ubench_queue_rw 4294967296 $g >> gpurun_out/r02_ubench_queue_rw.txt; done
     tools/ubench_d2d > gpurun_out/r02_ubench_d2d.txt; tools/ubench_d2d 1073741824 >> gpurun_out/r02_ubench_d2d.txt
-    tools/ubench_latency > gpurun_out/r02_ubench_latency.txt ;;
+    tools/archive/ubench_latency > gpurun_out/r02_ubench_latency.txt ;;
 host)         # r02_sweep_pinned_routes.txt, r02_sweep_staged_routes.txt, r02_configs.json, r02_bench_hostcall_latency.txt
-    python3 tools/sweep_pinned.py > gpurun_out/r02_sweep_pinned.log
-    python3 tools/sweep_pinned.py staged > gpurun_out/r02_sweep_staged.log
+    python3 tools/archive/sweep_pinned.py > gpurun_out/r02_sweep_pinned.log
+    python3 tools/archive/sweep_pinned.py staged > gpurun_out/r02_sweep_staged.log
     python3 tools/bench_configs.py --out gpurun_out/r02_configs.json
-    python3 tools/bench_hostcall.py > gpurun_out/r02_hostcall.txt ;;
+    python3 tools/archive/bench_hostcall.py > gpurun_out/r02_hostcall.txt ;;
 *) echo "usage: tools/reproduce_r02.sh build | bench | kernel | trace | ceilings | host" ;;
 esac

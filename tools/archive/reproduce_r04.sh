@@ -42,10 +42,10 @@ tk)           # the product kernel with the ticket fetched at the start of the t
     python3 bench.py --no-cpu-baseline > $O/r04_tk_bench.json
     python3 tools/bench_sizes.py > $O/r04_tk_bench_sizes.txt ;;
 memside)      # profiles/r04_memside_counters.json
-    bash tools/memside_counters.sh 4294967296 ;;
+    bash tools/archive/memside_counters.sh 4294967296 ;;
 staged)       # profiles/r04_staged_midsize.txt
     modulate_amd/bin/modbench --hostcall --trace > $O/r04_hostcall_trace.txt
-    python3 tools/sweep_midsize_host.py > $O/r04_sweep_midsize_host.txt ;;
+    python3 tools/archive/sweep_midsize_host.py > $O/r04_sweep_midsize_host.txt ;;
 crossover)    # profiles/r04_small_call_crossover.txt: both engines per call, the table MODGPU_HOST_POLICY=fastest decides by
     modulate_amd/bin/modbench --hostcall > $O/r04_hostcall.txt
     MODGPU_HOST_CGROUP=0 modulate_amd/bin/modbench --hostcall > $O/r04_hostcall_nocgroup.txt
@@ -59,6 +59,6 @@ extras)       # profiles/r04_first_pass.txt, r04_bench_big.txt, r04_handover.txt
     for p in h2d fill; do timeout -k 10 120 tools/first_pass series 4294967296 16 $p > $O/r04_series_$p.txt; done
     timeout -k 10 400 tools/first_pass first > $O/r04_first.txt
     timeout -k 10 600 python3 tools/bench_big.py > $O/r04_bench_big.txt
-    timeout -k 10 300 python3 tools/handover.py > $O/r04_handover.txt ;;
+    timeout -k 10 300 python3 tools/archive/handover.py > $O/r04_handover.txt ;;
 *) echo "usage: tools/reproduce_r04.sh build | bench | tail | tail2 | tk | memside | staged | crossover | parity | files | extras" ;;
 esac

@@ -11,7 +11,7 @@ build)        # on the build box (cross-compiles without a GPU); the binaries tr
 pcie)         # profiles/r05_pcie_route_*.json: rocprofv3 under the routes host-resident data really takes.
               # The program stands directly behind `--` (no env / shell hop under the profiler).
     TAG=${2:-r05}
-    timeout -k 10 120 tools/ubench_pcie_bidir > $O/${TAG}_pcie_bidir.txt 2>&1 || true
+    timeout -k 10 120 tools/archive/ubench_pcie_bidir > $O/${TAG}_pcie_bidir.txt 2>&1 || true
     for spec in "pinned 411 10" "pinned 4096 6" "staged 16 20" "staged 64 20" "staged 256 10" "staged 1024 6"; do
       set -- $spec
       D=$O/${TAG}_pcie_$1_$2
@@ -29,9 +29,9 @@ pcie)         # profiles/r05_pcie_route_*.json: rocprofv3 under 
     find $D -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_pcie_route_config4_kernel_trace.csv
     rm -rf $D ;;
 feed)         # profiles/r05_pcie_persist.txt, r05_pcie_feed.txt, r05f_pcie_route_staged_*: one host-fed kernel per pageable call
-    for m in 64 16 256 1024; do timeout -k 10 100 taskset -c 64-127,192-255 tools/ubench_pcie_persist $m 12 >> $O/r05_persist.txt; done
+    for m in 64 16 256 1024; do timeout -k 10 100 taskset -c 64-127,192-255 tools/archive/ubench_pcie_persist $m 12 >> $O/r05_persist.txt; done
     timeout -k 10 300 taskset -c 64-127,192-255 python3 tools/ab_feed.py 10 > $O/r05_ab_feed.txt
-    bash tools/profile_feed.sh ;;
+    bash tools/archive/profile_feed.sh ;;
 grid)         # profiles/r05_pcie_grid.txt: workgroups of a launch across PCIe, lanes, and how a staged stream is cut
     timeout -k 10 420 python3 tools/sweep_pcie_grid.py grid > $O/r05_sweep_grid.txt
     timeout -k 10 300 python3 tools/sweep_pcie_grid.py cut > $O/r05_sweep_cut.txt ;;
@@ -39,8 +39,8 @@ wake)         # profiles/r05_first_launch.txt: the chip's first launch after an 
     timeout -k 10 200 tools/first_pass wake 411000000 9 1500 > $O/r05_wake_411MB.txt
     timeout -k 10 200 tools/first_pass wake 4294967296 5 1500 > $O/r05_wake_4GiB.txt
     timeout -k 10 200 tools/first_pass wake 411000000 9 100 > $O/r05_wake_411MB_idle100ms.txt
-    timeout -k 10 500 python3 tools/first_launch_where.py 4 > $O/r05_first_launch_where.txt   # run F: events ...
-    bash tools/first_launch_trace.sh ;;                                                        # ... against the dispatches' own timestamps
+    timeout -k 10 500 python3 tools/archive/first_launch_where.py 4 > $O/r05_first_launch_where.txt   # run F: events ...
+    bash tools/archive/first_launch_trace.sh ;;                                                        # ... against the dispatches' own timestamps
 lsp)          # profiles/r05_lsp.txt: the next chunk's loads spread over the trip, every row validated
     for n in 4294967296 411000000; do
       TUNE_ONLY="LSP|PRODUCT modgpu_cycle_queue" timeout -k 10 400 tools/tune_cycle $n 9 > $O/r05_lsp_$n.txt
@@ -49,7 +49,7 @@ lspcounters)  # profiles/r05_lsp_counters.json: reads in flight and fabric read 
     D=$O/lspc; rm -rf $D; mkdir -p $D
     timeout -k 10 240 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_CYCLE_sum --output-format csv -d $D/pass1 -- tools/ubench_queue_rw 4294967296 200 2 > $D/pass1.log 2>&1
     timeout -k 10 120 tools/ubench_queue_rw 4294967296 200 8 > $D/rates.txt 2>&1
-    python3 tools/summarize_memside.py $D > $O/r05_lsp_counters.json ;;
+    python3 tools/archive/summarize_memside.py $D > $O/r05_lsp_counters.json ;;
 config5)      # profiles/r05_config5_kernels.json: every kernel of configs 4 and 5 end to end (pack, save, load, extract, rebuild, save) under rocprofv3
     D=$O/r05_c5; rm -rf $D
     timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 tools/bench_configs.py --sections c4,c5 --out $O/r05_config5_under_rocprofv3.json > $O/r05_config5.log 2>&1

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Distil tools/memside_counters.sh's rocprofv3 CSVs: per kernel (read-only / write-only / copy / product) the median per-launch
+"""Distil tools/archive/memside_counters.sh's rocprofv3 CSVs: per kernel (read-only / write-only / copy / product) the median per-launch
 value of every counter collected, plus the derived figures DESIGN 10 quotes.  Usage: summarize_memside.py gpurun_out/memside"""
 import csv
 import glob
@@ -33,7 +33,7 @@ def main():
                 disp[(lab, r["Counter_Name"], r["Dispatch_Id"])] += float(r["Counter_Value"])
         for (lab, c, _), v in disp.items():
             per[lab][c].append(v)
-    out = {"source": "tools/memside_counters.sh (rocprofv3 --pmc, one pass per group) over tools/ubench_queue_rw", "kernels": {}}
+    out = {"source": "tools/archive/memside_counters.sh (rocprofv3 --pmc, one pass per group) over tools/ubench_queue_rw", "kernels": {}}
     for lab, cs in per.items():
         out["kernels"][lab] = {c: sorted(v)[len(v) // 2] for c, v in sorted(cs.items())}
     for name in ("status.txt", "rates.txt"):

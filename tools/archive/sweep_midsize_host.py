@@ -2,13 +2,13 @@
 """Pageable host buffers of 16-256 MiB through modgpu_cycle_host (staged route: memcpy -> pinned slot -> kernel over PCIe ->
 memcpy back) by slot size and pipeline count -- one child process per setting (the tunables are latched at load).
 
-    python tools/sweep_midsize_host.py
+    python tools/archive/sweep_midsize_host.py
 """
 import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r"""
 import sys, time, numpy as np
 sys.path.insert(0, %r)

@@ -8,7 +8,7 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SIZES = (64 << 20, 411 << 20, 1 << 30, 1 << 32)
 CHILD = r'''
 import sys, time, numpy as np

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""tools/where_pinned_lands.py -- on which NUMA node does the runtime put page-locked memory (hipHostMalloc), seen from a thread on each node?
+"""tools/archive/where_pinned_lands.py -- on which NUMA node does the runtime put page-locked memory (hipHostMalloc), seen from a thread on each node?
 The staging set "next to the GPU" takes its slots from hipHostMalloc and binds its workers to the node sysfs names for the GPU: if the two
 disagree every staging copy crosses the socket link.  Prints the node of the first / middle / last page of an 8 MiB allocation."""
 import ctypes
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import modulate_amd as M  # noqa: E402
 import hip_rt  # noqa: E402
 
