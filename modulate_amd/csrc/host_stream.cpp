@@ -899,6 +899,330 @@ int finish_on_host(const Job &j, uint64_t *bytes_done)
 }
 } // namespace
 
+// ---- one call -------------------------------------------------------------------------------------------------------------------
+// stream_impl: resolve the device and the staging set, then one of three shapes of call:
+//   in_place_on_locked_pages   page-locked caller memory, in place: ONE kernel across PCIe on the pages themselves
+//   one_slot_call              header-sized buffers (what the reference's three call sites pass): one slot, one launch
+//   pipelined_call             everything else: the stream cut into pieces for up to kPipes pipelines on one of the five routes
+//                              above (plan_route says which), then -- if the GPU was lost under way -- the rescue
+namespace {
+struct CallCtx {
+    const Endpoint &src, &dst;
+    const uint64_t n;
+    const int32_t key;
+    const uint64_t stream_off;
+    const int dev;
+    Staging &s;
+    const bool identity, in_place, src_direct, dst_direct, all_direct, host_may_finish;
+    int copy_node = -1;
+    cpu_set_t caller_mask;
+    bool have_mask = false;
+    StreamOutcome &outcome;
+    void account(uint64_t host_bytes = 0) const
+    {
+        g_stats.gpu_calls.fetch_add(1, std::memory_order_relaxed);
+        g_stats.gpu_bytes.fetch_add(n - host_bytes, std::memory_order_relaxed);
+        (all_direct ? g_stats.direct_bytes : g_stats.staged_bytes).fetch_add(n - host_bytes, std::memory_order_relaxed);
+    }
+};
+int injected_here() { return fail(MODGPU_ERR_HIP, "injected failure (modgpu_debug_inject_failure_at)"); }
+
+// Page-locked caller memory of any size, cycled where it lies (default for such memory: 50 GB/s of payload against 26-29 for the
+// DMA ring and 30 for the staged route, profiles/r02_sweep_pinned_routes.txt; pinned mode 1 of the testing flavour keeps the DMA ring
+// selectable).  One launch + one sync; the kernel reads and writes the pages across PCIe itself (they are device-visible).
+int in_place_on_locked_pages(CallCtx &c)
+{
+    SlotLease lease(c.s);
+    lease.acquire(1, 1);
+    const int slot = lease.ids[0];
+    int rc = staging_reserve(c.s, lease.ids, 0, false, false);
+    if (rc) return rc;
+    void *mapped = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&mapped, c.src.mem, 0));
+    if (injected_at(0, 1, MODGPU_STAGE_FILL) || injected_at(0, 1, MODGPU_STAGE_LAUNCH)) return injected_here();
+    rc = cycle_device_impl(mapped, c.n, c.key, c.stream_off, c.s.stream[slot], /*over_pcie=*/true);
+    if (rc) return rc; // nothing was launched: the caller's pages are as they were
+    trace(MODGPU_TRACE_LAUNCHED, -1, 0, c.n);
+    // From here on the kernel writes the caller's pages itself.  If the wait for it fails nobody knows which of them it
+    // reached before it died, and the plaintext exists nowhere else: THIS route cannot be finished by the host loop, the error
+    // stands (include/modgpu.h says so at modgpu_cycle_auto_host).
+    c.outcome.touched = true;
+    hipError_t e = injected_at(0, 1, MODGPU_STAGE_SYNC) ? hipErrorLaunchFailure : hipStreamSynchronize(c.s.stream[slot]);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(c.s.stream[slot]);
+        return fail_hip(e, "hipStreamSynchronize (kernel over PCIe on the caller's page-locked memory)");
+    }
+    c.account();
+    return MODGPU_OK;
+}
+
+// Header-sized buffers (<= zero_copy_max): one slot, one kernel across PCIe on the slot, no workers.  The caller's bytes change
+// only after the wait has succeeded: the slot takes whatever damage a dying kernel does.
+int one_slot_call(CallCtx &c)
+{
+    Staging &s = c.s;
+    SlotLease lease(s);
+    lease.acquire(1, 1);
+    const int slot = lease.ids[0];
+    int rc = staging_reserve(s, lease.ids, c.n, false, true);
+    if (rc) return rc;
+    if (s.pinned_cap[slot] < c.n) return fail(MODGPU_ERR_INVALID, "staging slot smaller than the zero-copy buffer");
+    void *mapped = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&mapped, s.pinned[slot], 0));
+    if (injected_at(0, 1, MODGPU_STAGE_FILL)) return injected_here();
+    std::memcpy(s.pinned[slot], c.src.mem, c.n);
+    rc = injected_at(0, 1, MODGPU_STAGE_LAUNCH) ? injected_here() : cycle_device_impl(mapped, c.n, c.key, c.stream_off, s.stream[slot], /*over_pcie=*/true);
+    hipError_t e = hipStreamSynchronize(s.stream[slot]);
+    if (rc) return rc;
+    if (e == hipSuccess && (injected_at(0, 1, MODGPU_STAGE_SYNC) || injected_at(0, 1, MODGPU_STAGE_DRAIN))) e = hipErrorLaunchFailure;
+    if (e != hipSuccess) return fail_hip(e, "hipStreamSynchronize (kernel over PCIe)"); // the caller's buffer is as it was
+    c.outcome.touched = true;
+    std::memcpy(c.dst.mem, s.pinned[slot], c.n);
+    c.account();
+    return MODGPU_OK;
+}
+
+// Which route a pipelined call takes, the size of its pieces, and (feed_in_dst) how many bytes lie in front of the destination's
+// first 16-byte boundary.
+struct RoutePlan {
+    Route route;
+    uint64_t chunk, head;
+    bool memory_schedule; // cut and queued like a memory-to-memory call: ~64 chunks of >= 1 MiB, ramped, kernels on shared lanes
+};
+RoutePlan plan_route(CallCtx &c)
+{
+    const Endpoint &src = c.src, &dst = c.dst;
+    const uint64_t n = c.n;
+    // slot size: the whole buffer if it is small, else ~n/split between chunk_min and the cap (8 MiB by default).
+    // Memory on both sides, and file -> memory: ~64 chunks of >= 1 MiB, ramped, kernels on shared lanes (profiles/r05_pcie_grid.txt).
+    // Memory -> file and file -> file: ~16 chunks of >= 4 MiB, all alike, a stream per slot -- there the slow stage is pwrite,
+    // which wants few large calls (profiles/r04_file_routes.txt, r05_file_routes.txt).
+    RoutePlan p{};
+    p.memory_schedule = (src.mem && dst.mem) || (kFileSched != 0 && !src.mem && dst.mem);
+    const uint64_t split = p.memory_schedule ? kSplit : 16, chunk_min = p.memory_schedule ? kChunkMin : std::min<uint64_t>(4ull << 20, kChunk);
+    p.chunk = n <= chunk_min ? std::max<uint64_t>(n, 1ull << 20) : std::min<uint64_t>(kChunk, std::max<uint64_t>(chunk_min, ((n / split) + 0xFFFFF) & ~0xFFFFFull));
+    p.chunk = std::min<uint64_t>(p.chunk, kChunk);
+    // Default routes (profiles/r03_file_routes.txt, r06_file_routes.txt): pageable memory and files are copied / read into a pinned
+    // slot and cycled there across PCIe; a file that ends in page-locked caller memory is read straight into that memory and cycled
+    // where it lies; page-locked caller memory that ends in a file is DMA'd.  (Testing flavour, staged mode 1: the DMA form -- H2D,
+    // kernel in HBM, D2H -- of the first two.)
+    p.route = c.dst_direct && !src.mem && !c.identity && staged_mode() != 1 ? Route::in_dst
+              : !c.src_direct && !c.dst_direct && staged_mode() != 1        ? Route::slot_kernel
+                                                                            : Route::dma;
+    // A pageable (or file) source that ends in memory: ONE host-fed kernel for the whole call (cycle_feed_kernel.h) instead of a launch
+    // per chunk.  Uniform chunks -- as small as the flag words allow, since no chunk costs a launch -- of whole pieces; a call too large
+    // for that (or staged mode 1 / 2 of the testing flavour, or feed switched off) keeps the launch-per-chunk schedule.  The kernel draws
+    // chunks in stream order and waits for whichever pipeline owns the next one, so the pipelines must really run side by side: a
+    // staging set that cannot have its worker threads does not take these routes.
+    const bool feedable = kFeed != 0 && staged_mode() == 0 && !c.identity && dst.mem && (src.mem ? !c.src_direct && !c.dst_direct : kFileFeed != 0);
+    if (feedable && (p.route == Route::slot_kernel || p.route == Route::in_dst)) {
+        const uint64_t piece = kFeedPieceBytes;
+        const uint64_t fc = std::max<uint64_t>((kFeedChunk + piece - 1) / piece * piece, ((n + kFeedChunksMax - 1) / kFeedChunksMax + piece - 1) / piece * piece);
+        const int pipes_wanted = (int)std::min<uint64_t>((uint64_t)kPipes, ((n + fc - 1) / fc + 1) / 2);
+        const uint64_t head = p.route == Route::in_dst ? (16 - (reinterpret_cast<uintptr_t>(dst.mem) & 15)) & 15 : 0;
+        if (fc <= kChunk && (n + piece - 1) / piece < kFeedPiecesMax && (n < kFeedBelow || p.route == Route::in_dst) && n > head + piece &&
+            (pipes_wanted <= 1 || ensure_workers(c.s, pipes_wanted - 1, c.dev, physical_of(c.dev), c.caller_mask, c.have_mask) >= pipes_wanted - 1)) {
+            p.chunk = fc;
+            p.head = head;
+            p.route = p.route == Route::in_dst ? Route::feed_in_dst : Route::feed;
+        }
+    }
+    return p;
+}
+
+// What a host-fed call needs around its pipelines: flag words cleared and handed to the job BEFORE the pipelines start, the one
+// launch, and -- whichever way the call ends -- the kernel gone and its counters back at zero before the slots are given back.
+struct FeedCall {
+    CallCtx &c;
+    Job &job;
+    const std::vector<int> &slots;
+    const RoutePlan &plan;
+    int pipes = 0, lead_slot = -1;
+    uint64_t chunks = 0;
+    int prepare(int pipes_)
+    {
+        Staging &s = c.s;
+        pipes = pipes_;
+        lead_slot = slots[0];
+        const int rc = feed_reserve(s, lead_slot);
+        if (rc) return rc;
+        chunks = job.plan.size();
+        uint32_t *const flags = s.feed_flags[lead_slot];
+        std::memset(flags, 0, chunks * sizeof(uint32_t));
+        std::memset(flags + kFeedChunksMax, 0, chunks * sizeof(uint32_t));
+        flags[2 * kFeedChunksMax] = 0;
+        job.feed_ready = flags;
+        job.feed_done = flags + kFeedChunksMax;
+        job.feed_abort = flags + 2 * kFeedChunksMax;
+        job.feed_stream = s.stream[lead_slot];
+        return MODGPU_OK;
+    }
+    // (~15 us of host time: made after the workers have been posted, while every pipeline copies its first chunk in -- the kernel is
+    //  there by the time the first chunk is marked ready, and a 4 MiB call is 20 us shorter than with the launch in front,
+    //  profiles/r05_pcie_feed.txt)
+    int launch()
+    {
+        Staging &s = c.s;
+        CycleFeedArgs a{};
+        if (plan.route == Route::feed_in_dst) { // the chunks are read to where they belong: the kernel's stream starts at the destination's first 16-byte boundary
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&a.slot[0]), c.dst.mem, 0));
+            a.slot[0] += plan.head;
+        } else
+            for (int k = 0; k < pipes * 2; ++k) HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&a.slot[k]), s.pinned[slots[(size_t)k]], 0));
+        a.ready = s.feed_flags_dev[lead_slot];
+        a.done = s.feed_flags_dev[lead_slot] + kFeedChunksMax;
+        a.abort = s.feed_flags_dev[lead_slot] + 2 * kFeedChunksMax;
+        a.work = s.feed_work[lead_slot]; // (all zero: feed_reserve, finish)
+        a.n = c.n - plan.head;
+        a.patience_ticks = kFeedPatienceTicks;
+        a.chunk_bytes = (uint32_t)plan.chunk;
+        a.pipes = plan.route == Route::feed_in_dst ? 0u : (uint32_t)pipes;
+        a.head = (uint32_t)plan.head;
+        a.base_head = lcg::state_residue(lcg::key_residue(c.key), c.stream_off);
+        a.base = lcg::state_residue(lcg::key_residue(c.key), c.stream_off + plan.head);
+        const uint32_t pieces = (uint32_t)((a.n + kFeedPieceBytes - 1) / kFeedPieceBytes);
+        const uint32_t grid = std::min<uint32_t>(kFeedGrid, pieces);
+        const hipError_t e = modgpu_launch_cycle_feed(a, grid, job.feed_stream);
+        if (e != hipSuccess) return fail_hip(e, "cycle kernel launch (host-fed)");
+        job.feed_launched.store(true, std::memory_order_release);
+        note_feed_launch(grid, c.n);
+        trace(MODGPU_TRACE_LAUNCHED, -1, 0, c.n);
+        return MODGPU_OK;
+    }
+    void finish(int rc)
+    {
+        Staging &s = c.s;
+        if (rc == MODGPU_OK) {
+            // every chunk is done and drained: the kernel has drawn its last ticket and leaves by itself.  (An error here cannot undo the
+            //  result, which is whole in the destination: it is cleared, and the next call on this device meets whatever is wrong with it.)
+            if (hipStreamSynchronize(job.feed_stream) != hipSuccess) (void)hipGetLastError();
+        } else { // whichever pipeline failed has told the kernel to leave and waited for it; make sure before the slots go back
+            __atomic_store_n(job.feed_abort, 1u, __ATOMIC_RELEASE);
+            const std::string keep = t_err;
+            (void)hipStreamSynchronize(job.feed_stream);
+            (void)hipGetLastError();
+            t_err = keep;
+        }
+        // the counters go back to zero behind the call (asynchronously, on the slot's own stream: in front of its next launch)
+        if (hipMemsetAsync(s.feed_work[lead_slot], 0, (chunks + 2) * sizeof(uint32_t), job.feed_stream) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(s.feed_work[lead_slot]); // (cannot be trusted any more: the next call that leads with this slot makes new ones)
+            s.feed_work[lead_slot] = nullptr;
+        }
+    }
+};
+
+// The GPU was lost after the call had begun.  Every pipeline has stopped and waited for what it had in flight.  A piece is either
+// marked done -- its result is in the destination, whole -- or not, and then the host loop can still do it as long as its plaintext
+// is still somewhere: in the source file, in the caller's other buffer, or in the destination itself when that is only ever written
+// by a finished piece's copy out of its slot (the staged routes).  In place AND written directly by the device (page-locked memory
+// in DMA mode) the plaintext of an unfinished piece is gone: the error stands.
+int rescue_on_host(CallCtx &c, const Job &job, int rc)
+{
+    const bool recoverable = rc == MODGPU_ERR_HIP && !(c.in_place && job.dst_written_by_device());
+    if (!c.host_may_finish || !recoverable) return rc;
+    const std::string why = t_err;
+    uint64_t host_bytes = 0;
+    const int rc2 = finish_on_host(job, &host_bytes);
+    if (rc2 != MODGPU_OK) return rc2; // (an I/O error of the rescue itself: its own text)
+    c.outcome.finished_on_host = true;
+    c.outcome.host_bytes = host_bytes;
+    c.outcome.touched = true;
+    c.account(host_bytes);
+    g_stats.midcall_rescues.fetch_add(1, std::memory_order_relaxed);
+    g_stats.midcall_rescued_bytes.fetch_add(host_bytes, std::memory_order_relaxed);
+    g_stats.scalar_bytes.fetch_add(host_bytes, std::memory_order_relaxed);
+    t_err = "finished on the host loop after: " + why;
+    return MODGPU_OK;
+}
+
+int pipelined_call(CallCtx &c)
+{
+    Staging &s = c.s;
+    const RoutePlan plan = plan_route(c);
+    const bool feed = plan.route == Route::feed || plan.route == Route::feed_in_dst;
+    const uint64_t n_chunks = (c.n - plan.head + plan.chunk - 1) / plan.chunk;
+    Job job(c.src, c.dst, c.n, plan.chunk, c.key, c.stream_off);
+    job.route = plan.route;
+    int pipes, ring;
+    if (c.all_direct && c.src.mem && c.dst.mem) { // no host work at all: one thread keeps a ring of slots busy
+        pipes = 1;
+        ring = (int)std::min<uint64_t>((uint64_t)kRing, std::max<uint64_t>(n_chunks, 2));
+    } else {
+        pipes = (int)std::min<uint64_t>((uint64_t)kPipes, (n_chunks + 1) / 2); // a pipeline is worth >= 2 chunks
+        ring = 2;
+    }
+    // a destination file gets its blocks before eight threads write into it at once (tmpfs and most file systems
+    // allocate under one lock: parallel extending writes serialise there)
+    if (c.dst.fd >= 0 && c.n >= (8ull << 20)) (void)::posix_fallocate(c.dst.fd, (off_t)c.dst.base, (off_t)c.n);
+    // this call's slots: what it would like, or as many whole pipelines as are free right now (another caller may be at work
+    // on this GPU), at least one
+    SlotLease lease(s);
+    lease.acquire(pipes * ring, ring);
+    pipes = (int)lease.ids.size() / ring;
+    job.set_plan(cut_stream(c.n, plan.chunk, pipes, plan.memory_schedule && !feed ? kRamp : 0, plan.head));
+    job.copy_node = c.copy_node;
+    job.have_mask = c.have_mask;
+    if (c.have_mask) job.caller_mask = c.caller_mask;
+    for (int k = 0; k < (feed ? 0 : plan.memory_schedule ? kLanes : kFileLanes) && k < (int)lease.ids.size(); ++k) job.lanes.push_back(nullptr); // (streams exist after staging_reserve)
+    trace(MODGPU_TRACE_SLOTS, -1, (uint64_t)pipes, plan.chunk);
+    const bool works_in_dst = plan.route == Route::in_dst || plan.route == Route::feed_in_dst;
+    int rc = staging_reserve(s, lease.ids, plan.chunk, plan.route == Route::dma, !(c.src_direct && c.dst_direct) && !works_in_dst);
+    if (rc) return rc;
+    for (size_t k = 0; k < job.lanes.size(); ++k) job.lanes[k] = s.stream[lease.ids[k]];
+    FeedCall fed{c, job, lease.ids, plan};
+    if (feed) {
+        rc = fed.prepare(pipes);
+        if (rc) return rc;
+    }
+
+    if (pipes <= 1) {
+        if (feed) {
+            rc = fed.launch();
+            if (rc) return rc; // nothing of the caller's has been touched
+        }
+        rc = run_pipe(s, lease.ids.data(), ring, job, 0, 1);
+        if (rc == kStopped) rc = MODGPU_OK;
+    } else {
+        auto call = std::make_shared<Call>(s, job, pipes, ring, physical_of(c.dev), lease.ids);
+        const int workers = ensure_workers(s, pipes - 1, c.dev, physical_of(c.dev), c.caller_mask, c.have_mask);
+        post_to_workers(s, call, std::min(pipes - 1, workers)); // (pipelines nobody is there for are run by this thread, after its own)
+        trace(MODGPU_TRACE_POSTED, -1, (uint64_t)pipes, 0);
+        int rc_launch = MODGPU_OK;
+        std::string launch_err;
+        if (feed) {
+            rc_launch = fed.launch();
+            if (rc_launch) { // no kernel: the pipelines stop at their next step; none has drained anything (nothing was ever marked done)
+                launch_err = t_err;
+                job.failed.store(true, std::memory_order_release);
+            }
+        }
+        call->help(false); // pipeline 0 starts now, on the calling thread; then whatever no worker has picked up yet
+        call->wait();
+        { // entries of this call that no worker has picked up are of no use to anybody now
+            std::lock_guard<std::mutex> lock(s.mu);
+            s.requests.erase(std::remove(s.requests.begin(), s.requests.end(), call), s.requests.end());
+        }
+        for (int p = 0; p < pipes && rc == MODGPU_OK; ++p)
+            if (call->rcs[(size_t)p]) {
+                t_err = call->errs[(size_t)p];
+                rc = call->rcs[(size_t)p];
+            }
+        if (rc_launch) {
+            t_err = launch_err;
+            rc = rc_launch;
+        }
+    }
+    c.outcome.touched = job.touched.load();
+    if (feed) fed.finish(rc);
+    if (rc == MODGPU_OK) {
+        c.account();
+        return rc;
+    }
+    return rescue_on_host(c, job, rc);
+}
+} // namespace
+
 int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t key, uint64_t stream_off, int device,
                 bool host_may_finish, StreamOutcome *out)
 {
@@ -946,261 +1270,11 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     trace(MODGPU_TRACE_CALL_BEGIN, -1, 0, n);
     struct CallEnd { uint64_t n; ~CallEnd() { trace(MODGPU_TRACE_CALL_END, -1, 0, n); } } call_end{n};
 
-    const bool all_direct = (!src.mem || src_direct) && (!dst.mem || dst_direct);
-    auto account = [&] {
-        g_stats.gpu_calls.fetch_add(1, std::memory_order_relaxed);
-        g_stats.gpu_bytes.fetch_add(n, std::memory_order_relaxed);
-        (all_direct ? g_stats.direct_bytes : g_stats.staged_bytes).fetch_add(n, std::memory_order_relaxed);
-    };
-
-    // ---- kernel over PCIe: header-sized buffers (what the reference's three call sites pass, <= 512 KiB),
-    // and pinned caller memory of any size when that mode is selected.  One launch + one sync; the
-    // kernel reads and writes the pinned pages across PCIe itself (they are device-visible).
-    // (default for pinned memory: measured 50 GB/s of payload against 26-29 for the DMA ring below and
-    //  30 for the staged route, profiles/r02_sweep_pinned_routes.txt; mode 1 keeps the DMA ring selectable)
-    const int mode = pinned_mode();
-    if (in_place && src_direct && !identity && (n <= kZeroCopyMax || mode != 1)) {
-        SlotLease lease(s);
-        lease.acquire(1, 1);
-        const int slot = lease.ids[0];
-        rc = staging_reserve(s, lease.ids, 0, false, false);
-        if (rc) return rc;
-        void *mapped = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(&mapped, src.mem, 0));
-        if (injected_at(0, 1, MODGPU_STAGE_FILL) || injected_at(0, 1, MODGPU_STAGE_LAUNCH)) return fail(MODGPU_ERR_HIP, "injected failure (modgpu_debug_inject_failure_at)");
-        rc = cycle_device_impl(mapped, n, key, stream_off, s.stream[slot], /*over_pcie=*/true);
-        if (rc) return rc; // nothing was launched: the caller's pages are as they were
-        trace(MODGPU_TRACE_LAUNCHED, -1, 0, n);
-        // From here on the kernel writes the caller's pages itself.  If the wait for it fails nobody knows which of them it
-        // reached before it died, and the plaintext exists nowhere else: THIS route cannot be finished by the host loop, the error
-        // stands (include/modgpu.h says so at modgpu_cycle_auto_host).
-        outcome.touched = true;
-        hipError_t e = injected_at(0, 1, MODGPU_STAGE_SYNC) ? hipErrorLaunchFailure : hipStreamSynchronize(s.stream[slot]);
-        if (e != hipSuccess) {
-            (void)hipStreamSynchronize(s.stream[slot]);
-            return fail_hip(e, "hipStreamSynchronize (kernel over PCIe on the caller's page-locked memory)");
-        }
-        account();
-        return MODGPU_OK;
-    }
-    if (n <= kZeroCopyMax && src.mem && dst.mem && !identity) {
-        SlotLease lease(s);
-        lease.acquire(1, 1);
-        const int slot = lease.ids[0];
-        rc = staging_reserve(s, lease.ids, n, false, true);
-        if (rc) return rc;
-        if (s.pinned_cap[slot] < n) return fail(MODGPU_ERR_INVALID, "staging slot smaller than the zero-copy buffer");
-        void *mapped = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(&mapped, s.pinned[slot], 0));
-        if (injected_at(0, 1, MODGPU_STAGE_FILL)) return fail(MODGPU_ERR_HIP, "injected failure (modgpu_debug_inject_failure_at)");
-        std::memcpy(s.pinned[slot], src.mem, n);
-        rc = injected_at(0, 1, MODGPU_STAGE_LAUNCH) ? fail(MODGPU_ERR_HIP, "injected failure (modgpu_debug_inject_failure_at)")
-                                                     : cycle_device_impl(mapped, n, key, stream_off, s.stream[slot], /*over_pcie=*/true);
-        hipError_t e = hipStreamSynchronize(s.stream[slot]);
-        if (rc) return rc;
-        if (e == hipSuccess && (injected_at(0, 1, MODGPU_STAGE_SYNC) || injected_at(0, 1, MODGPU_STAGE_DRAIN))) e = hipErrorLaunchFailure;
-        if (e != hipSuccess) return fail_hip(e, "hipStreamSynchronize (kernel over PCIe)"); // the caller's buffer is as it was: the slot took the damage
-        outcome.touched = true;
-        std::memcpy(dst.mem, s.pinned[slot], n);
-        account();
-        return MODGPU_OK;
-    }
-
-    // slot size: the whole buffer if it is small, else ~n/split between chunk_min and the cap (8 MiB by default).
-    // Memory on both sides, and file -> memory: ~64 chunks of >= 1 MiB, ramped, kernels on shared lanes (profiles/r05_pcie_grid.txt).
-    // Memory -> file and file -> file: ~16 chunks of >= 4 MiB, all alike, a stream per slot -- there the slow stage is pwrite,
-    // which wants few large calls (profiles/r04_file_routes.txt, r05_file_routes.txt).
-    const bool mem_both = (src.mem && dst.mem) || (kFileSched != 0 && !src.mem && dst.mem); // (named for what it was: "takes the memory schedule")
-    const uint64_t split = mem_both ? kSplit : 16, chunk_min = mem_both ? kChunkMin : std::min<uint64_t>(4ull << 20, kChunk);
-    uint64_t chunk = n <= chunk_min ? std::max<uint64_t>(n, 1ull << 20)
-                                    : std::min<uint64_t>(kChunk, std::max<uint64_t>(chunk_min, ((n / split) + 0xFFFFF) & ~0xFFFFFull));
-    chunk = std::min<uint64_t>(chunk, kChunk);
-    // Default routes (profiles/r03_file_routes.txt, r06_file_routes.txt): pageable memory and files are copied / read into a pinned
-    // slot and cycled there across PCIe; a file that ends in page-locked caller memory is read straight into that memory and cycled
-    // where it lies; page-locked caller memory that ends in a file is DMA'd.  (Testing flavour, staged mode 1: the DMA form -- H2D,
-    // kernel in HBM, D2H -- of the first two.)
-    Route route = dst_direct && !src.mem && !identity && staged_mode() != 1 ? Route::in_dst
-                  : !src_direct && !dst_direct && staged_mode() != 1        ? Route::slot_kernel
-                                                                            : Route::dma;
-    // A pageable (or file) source that ends in memory: ONE host-fed kernel for the whole call (cycle_feed_kernel.h) instead of a launch
-    // per chunk.  Uniform chunks -- as small as the flag words allow, since no chunk costs a launch -- of whole pieces; a call too large
-    // for that (or staged mode 1 / 2 of the testing flavour, or feed switched off) keeps the launch-per-chunk schedule.  The kernel draws
-    // chunks in stream order and waits for whichever pipeline owns the next one, so the pipelines must really run side by side: a
-    // staging set that cannot have its worker threads does not take these routes.
-    const bool feedable = kFeed != 0 && staged_mode() == 0 && !identity && dst.mem && (src.mem ? !src_direct && !dst_direct : kFileFeed != 0);
-    uint64_t head = 0; // feed_in_dst: bytes of the destination in front of its first 16-byte boundary (they travel with chunk 0)
-    if (feedable && (route == Route::slot_kernel || route == Route::in_dst)) {
-        const uint64_t piece = kFeedPieceBytes;
-        const uint64_t c = std::max<uint64_t>((kFeedChunk + piece - 1) / piece * piece, ((n + kFeedChunksMax - 1) / kFeedChunksMax + piece - 1) / piece * piece);
-        const int pipes_wanted = (int)std::min<uint64_t>((uint64_t)kPipes, ((n + c - 1) / c + 1) / 2);
-        if (route == Route::in_dst) head = (16 - (reinterpret_cast<uintptr_t>(dst.mem) & 15)) & 15;
-        if (c <= kChunk && (n + piece - 1) / piece < kFeedPiecesMax && (n < kFeedBelow || route == Route::in_dst) && n > head + piece &&
-            (pipes_wanted <= 1 || ensure_workers(s, pipes_wanted - 1, dev, physical_of(dev), caller_mask, have_mask) >= pipes_wanted - 1)) {
-            chunk = c;
-            route = route == Route::in_dst ? Route::feed_in_dst : Route::feed;
-        } else head = 0;
-    }
-    const bool feed = route == Route::feed || route == Route::feed_in_dst;
-    const uint64_t n_chunks = (n - head + chunk - 1) / chunk;
-    Job job(src, dst, n, chunk, key, stream_off);
-    job.route = route;
-    int pipes, ring;
-    if (all_direct && src.mem && dst.mem) { // no host work at all: one thread keeps a ring of slots busy
-        pipes = 1;
-        ring = (int)std::min<uint64_t>((uint64_t)kRing, std::max<uint64_t>(n_chunks, 2));
-    } else {
-        pipes = (int)std::min<uint64_t>((uint64_t)kPipes, (n_chunks + 1) / 2); // a pipeline is worth >= 2 chunks
-        ring = 2;
-    }
-    // a destination file gets its blocks before eight threads write into it at once (tmpfs and most file systems
-    // allocate under one lock: parallel extending writes serialise there)
-    if (dst.fd >= 0 && n >= (8ull << 20)) (void)::posix_fallocate(dst.fd, (off_t)dst.base, (off_t)n);
-    // this call's slots: what it would like, or as many whole pipelines as are free right now (another caller may be at work
-    // on this GPU), at least one
-    SlotLease lease(s);
-    lease.acquire(pipes * ring, ring);
-    pipes = (int)lease.ids.size() / ring;
-    job.set_plan(cut_stream(n, chunk, pipes, mem_both && !feed ? kRamp : 0, head));
-    job.copy_node = copy_node;
-    job.have_mask = have_mask;
-    if (have_mask) job.caller_mask = caller_mask;
-    for (int k = 0; k < (feed ? 0 : mem_both ? kLanes : kFileLanes) && k < (int)lease.ids.size(); ++k) job.lanes.push_back(nullptr); // (streams exist after staging_reserve)
-    trace(MODGPU_TRACE_SLOTS, -1, (uint64_t)pipes, chunk);
-    const bool works_in_dst = route == Route::in_dst || route == Route::feed_in_dst;
-    rc = staging_reserve(s, lease.ids, chunk, route == Route::dma, !(src_direct && dst_direct) && !works_in_dst);
-    if (rc) return rc;
-    for (size_t k = 0; k < job.lanes.size(); ++k) job.lanes[k] = s.stream[lease.ids[k]];
-    // Host-fed call: the flag words are cleared and handed to the pipelines BEFORE these start; the launch itself (~15 us of host time)
-    // happens after the workers have been posted, while every pipeline copies its first chunk in -- the kernel is there by the time
-    // the first chunk is marked ready, and a 4 MiB call is 20 us shorter than with the launch in front (profiles/r05_pcie_feed.txt).
-    int lead_slot = -1;
-    uint64_t feed_chunks = 0;
-    auto launch_feed = [&]() -> int {
-        CycleFeedArgs a{};
-        if (route == Route::feed_in_dst) { // the chunks are read to where they belong: the kernel's stream starts at the destination's first 16-byte boundary
-            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&a.slot[0]), dst.mem, 0));
-            a.slot[0] += head;
-        } else
-            for (int k = 0; k < pipes * ring; ++k) HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&a.slot[k]), s.pinned[lease.ids[(size_t)k]], 0));
-        a.ready = s.feed_flags_dev[lead_slot];
-        a.done = s.feed_flags_dev[lead_slot] + kFeedChunksMax;
-        a.abort = s.feed_flags_dev[lead_slot] + 2 * kFeedChunksMax;
-        a.work = s.feed_work[lead_slot]; // (all zero: feed_reserve, feed_leave_clean)
-        a.n = n - head;
-        a.patience_ticks = kFeedPatienceTicks;
-        a.chunk_bytes = (uint32_t)chunk;
-        a.pipes = route == Route::feed_in_dst ? 0u : (uint32_t)pipes;
-        a.head = (uint32_t)head;
-        a.base_head = lcg::state_residue(lcg::key_residue(key), stream_off);
-        a.base = lcg::state_residue(lcg::key_residue(key), stream_off + head);
-        const uint32_t pieces = (uint32_t)((n - head + kFeedPieceBytes - 1) / kFeedPieceBytes);
-        const uint32_t grid = std::min<uint32_t>(kFeedGrid, pieces);
-        const hipError_t e = modgpu_launch_cycle_feed(a, grid, job.feed_stream);
-        if (e != hipSuccess) return fail_hip(e, "cycle kernel launch (host-fed)");
-        job.feed_launched.store(true, std::memory_order_release);
-        note_feed_launch(grid, n);
-        trace(MODGPU_TRACE_LAUNCHED, -1, 0, n);
-        return MODGPU_OK;
-    };
-    if (feed) {
-        lead_slot = lease.ids[0];
-        rc = feed_reserve(s, lead_slot);
-        if (rc) return rc;
-        feed_chunks = job.plan.size();
-        uint32_t *const flags = s.feed_flags[lead_slot];
-        std::memset(flags, 0, feed_chunks * sizeof(uint32_t));
-        std::memset(flags + kFeedChunksMax, 0, feed_chunks * sizeof(uint32_t));
-        flags[2 * kFeedChunksMax] = 0;
-        job.feed_ready = flags;
-        job.feed_done = flags + kFeedChunksMax;
-        job.feed_abort = flags + 2 * kFeedChunksMax;
-        job.feed_stream = s.stream[lead_slot];
-    }
-
-    if (pipes <= 1) {
-        if (feed) {
-            rc = launch_feed();
-            if (rc) return rc; // nothing of the caller's has been touched
-        }
-        rc = run_pipe(s, lease.ids.data(), ring, job, 0, 1);
-        if (rc == kStopped) rc = MODGPU_OK;
-    } else {
-        auto call = std::make_shared<Call>(s, job, pipes, ring, physical_of(dev), lease.ids);
-        const int workers = ensure_workers(s, pipes - 1, dev, physical_of(dev), caller_mask, have_mask);
-        post_to_workers(s, call, std::min(pipes - 1, workers)); // (pipelines nobody is there for are run by this thread, after its own)
-        trace(MODGPU_TRACE_POSTED, -1, (uint64_t)pipes, 0);
-        int rc_launch = MODGPU_OK;
-        std::string launch_err;
-        if (feed) {
-            rc_launch = launch_feed();
-            if (rc_launch) { // no kernel: the pipelines stop at their next step; none has drained anything (nothing was ever marked done)
-                launch_err = t_err;
-                job.failed.store(true, std::memory_order_release);
-            }
-        }
-        call->help(false); // pipeline 0 starts now, on the calling thread; then whatever no worker has picked up yet
-        call->wait();
-        { // entries of this call that no worker has picked up are of no use to anybody now
-            std::lock_guard<std::mutex> lock(s.mu);
-            s.requests.erase(std::remove(s.requests.begin(), s.requests.end(), call), s.requests.end());
-        }
-        for (int p = 0; p < pipes && rc == MODGPU_OK; ++p)
-            if (call->rcs[(size_t)p]) {
-                t_err = call->errs[(size_t)p];
-                rc = call->rcs[(size_t)p];
-            }
-        if (rc_launch) {
-            t_err = launch_err;
-            rc = rc_launch;
-        }
-    }
-    outcome.touched = job.touched.load();
-    if (feed) {
-        if (rc == MODGPU_OK) {
-            // every chunk is done and drained: the kernel has drawn its last ticket and leaves by itself.  (An error here cannot undo the
-            //  result, which is whole in the destination: it is cleared, and the next call on this device meets whatever is wrong with it.)
-            if (hipStreamSynchronize(job.feed_stream) != hipSuccess) (void)hipGetLastError();
-        } else { // whichever pipeline failed has told the kernel to leave and waited for it; make sure before the slots go back
-            __atomic_store_n(job.feed_abort, 1u, __ATOMIC_RELEASE);
-            const std::string keep = t_err;
-            (void)hipStreamSynchronize(job.feed_stream);
-            (void)hipGetLastError();
-            t_err = keep;
-        }
-    }
-    if (feed) { // the counters go back to zero behind the call (asynchronously, on the slot's own stream: in front of its next launch)
-        if (hipMemsetAsync(s.feed_work[lead_slot], 0, (feed_chunks + 2) * sizeof(uint32_t), job.feed_stream) != hipSuccess) {
-            (void)hipGetLastError();
-            (void)hipFree(s.feed_work[lead_slot]); // (cannot be trusted any more: the next call that leads with this slot makes new ones)
-            s.feed_work[lead_slot] = nullptr;
-        }
-    }
-    if (rc == MODGPU_OK) {
-        account();
-        return rc;
-    }
-    // ---- the GPU was lost after the call had begun.  Every pipeline has stopped and waited for what it had in flight.
-    // A piece is either marked done -- its result is in the destination, whole -- or not, and then the host loop can still do it
-    // as long as its plaintext is still somewhere: in the source file, in the caller's other buffer, or in the destination itself
-    // when that is only ever written by a finished piece's copy out of its slot (the staged route).  In place AND written
-    // directly by the device (page-locked memory in DMA mode) the plaintext of an unfinished piece is gone: the error stands.
-    const bool recoverable = rc == MODGPU_ERR_HIP && !(in_place && job.dst_written_by_device());
-    if (!host_may_finish || !recoverable) return rc;
-    const std::string why = t_err;
-    uint64_t host_bytes = 0;
-    const int rc2 = finish_on_host(job, &host_bytes);
-    if (rc2 != MODGPU_OK) return rc2; // (an I/O error of the rescue itself: its own text)
-    outcome.finished_on_host = true;
-    outcome.host_bytes = host_bytes;
-    outcome.touched = true;
-    g_stats.gpu_calls.fetch_add(1, std::memory_order_relaxed);
-    g_stats.gpu_bytes.fetch_add(n - host_bytes, std::memory_order_relaxed);
-    (all_direct ? g_stats.direct_bytes : g_stats.staged_bytes).fetch_add(n - host_bytes, std::memory_order_relaxed);
-    g_stats.midcall_rescues.fetch_add(1, std::memory_order_relaxed);
-    g_stats.midcall_rescued_bytes.fetch_add(host_bytes, std::memory_order_relaxed);
-    g_stats.scalar_bytes.fetch_add(host_bytes, std::memory_order_relaxed);
-    t_err = "finished on the host loop after: " + why;
-    return MODGPU_OK;
+    CallCtx c{src, dst, n, key, stream_off, dev, s, identity, in_place, src_direct, dst_direct,
+              (!src.mem || src_direct) && (!dst.mem || dst_direct), host_may_finish, copy_node, caller_mask, have_mask, outcome};
+    if (in_place && src_direct && !identity && (n <= kZeroCopyMax || pinned_mode() != 1)) return in_place_on_locked_pages(c);
+    if (n <= kZeroCopyMax && src.mem && dst.mem && !identity) return one_slot_call(c);
+    return pipelined_call(c);
 }
 
 } // namespace modgpu
