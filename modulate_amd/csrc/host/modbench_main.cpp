@@ -455,13 +455,13 @@ int Route( const std::string& kind, uint64_t mib, int reps )
         TRY( once() );
         walls.push_back( Now() - t0 );
     }
-    modgpu_host_trace( 0 );
     if( fromFile )
-    { // every call gave the same ciphertext; one more pass over it in memory must give the file's bytes back
+    { // every call gave the same ciphertext; one more pass over it in memory (an untimed call of its own in the launch list) must give the file's bytes back
         ::unlink( path.c_str() );
         TRY( modgpu_cycle_host( buf, n, kKey, 0, 0 ) );
         reps = 0; // (the restore check below: "an even number of passes")
     }
+    modgpu_host_trace( 0 );
     std::vector< double > sorted = walls;
     std::sort( sorted.begin(), sorted.end() );
     std::printf( "calls (after 2 untimed): best %.3f ms = %.2f GB/s, median %.3f ms = %.2f GB/s of payload (each byte crosses the link twice)\n", sorted.front() * 1e3,

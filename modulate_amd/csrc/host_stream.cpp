@@ -2,27 +2,25 @@
 // memory or in a file get through the kernel and back (include/modgpu.h: modgpu_cycle_host,
 // modgpu_cycle_file*, and through them CEncryptionCycler::Cycle and the CArk part cipher).
 //
-// Three routes, picked per call (rates: profiles/r05_pcie_route_*.json, one MI355X behind PCIe 5 x16):
+// Three shapes of call (stream_impl), rates in profiles/r06_pcie_route_*.json (one MI355X behind PCIe 5 x16; ceilings of the link in
+// profiles/r06_pcie_ceiling.txt: DMA 55 GB/s one way, 47 per direction both ways; one kernel in place 50.4):
 //
-//   pinned            the caller's pages are page-locked (modgpu_host_alloc): ONE kernel launch reads and
-//                     writes them across PCIe where they lie -- no host copy, no DMA submissions, no
-//                     device slots, no host threads.  50.2-50.4 GB/s of payload at 64 MiB .. 4 GiB, each byte
-//                     crossing the link twice.  (Testing flavour, pinned mode 1: chunked H2D -> kernel in HBM ->
-//                     D2H straight from / to the pages through a ring of device slots, 26-29 GB/s.)  When only
-//                     one side of a file stream is pinned memory, that side is DMA'd directly or -- file ->
-//                     page-locked memory -- read into the destination itself and cycled where it lies.
-//   pageable, large   copy -> pinned slot -> kernel across PCIe on the slot -> copy back, spread over kPipes
-//                     independent pipelines (host thread + two slots each, double-buffered).  Below 2 GiB the kernel is ONE
-//                     host-fed launch per call (cycle_feed_kernel.h): 256 KiB chunks, a pipeline marks its chunk ready in
-//                     page-locked memory and polls the chunk's done word -- 39.8 / 46.1 / 47.7 / 48.4 GB/s at 16 / 64 /
-//                     256 / 1024 MiB (profiles/r05f_pcie_route_staged_*).  From 2 GiB up, and with a file on either side, a
-//                     launch per chunk: ~64 pieces of >= 1 MiB (<= 8 MiB) behind a 512 KiB ramp, the kernels queued on 4
-//                     shared lanes (36.5 / 43.6 / 46.4 / 48.1 on the sizes above, profiles/r05_pcie_route_staged_*).
-//                     (Testing flavour, staged mode 1: copy -> H2D DMA -> kernel in HBM -> D2H DMA -> copy, round 1's form,
-//                     27-30 GB/s; mode 2: the launch per chunk everywhere.)
+//   in place on page-locked pages   the caller's pages are page-locked (modgpu_host_alloc): ONE kernel launch reads and writes them
+//                     across PCIe where they lie -- no host copy, no DMA submissions, no device slots, no host threads.  50.2-50.4 GB/s
+//                     of payload at 64 MiB .. 4 GiB, each byte crossing the link twice.  (Testing flavour, pinned mode 1: the DMA ring.)
+//   one slot          <= 1 MiB, what the reference's three call sites pass (headers): one slot, one kernel across PCIe, no workers.
+//   pipelined         everything else, cut into pieces for up to kPipes pipelines (host thread + two slots each) on one of five ROUTES
+//                     (enum Route; each a submit / wait pair over the shared core run_route):
+//                       feed         pageable memory, or a part file, that ends in pageable memory: copy / pread -> pinned slot -> the
+//                                    call's ONE host-fed kernel (cycle_feed_kernel.h) cycles the slot across PCIe -> copy out.  256 KiB
+//                                    chunks; a pipeline marks its chunk ready in page-locked memory and polls the chunk's done word.
+//                       feed_in_dst  a part file that ends in page-locked memory: pread lands in the destination, the one kernel
+//                                    cycles it there -- no slot, no copy.
+//                       slot_kernel  the same as feed with a LAUNCH PER CHUNK (~64 pieces of >= 1 MiB behind a 512 KiB ramp, kernels on
+//                                    4 shared lanes): calls of 2 GiB and more, memory -> file, file -> file, a set without worker threads.
+//                       in_dst       feed_in_dst with a launch per chunk (testing flavour: file_feed = 0).
+//                       dma          page-locked memory that is not cycled in place (e.g. -> file): H2D DMA -> kernel in HBM -> D2H DMA.
 //                     A file endpoint replaces its copy by pread / pwrite on the pinned slot.
-//   small (<= 1 MiB)  what the reference's three call sites pass (headers): one slot, one kernel across PCIe,
-//                     no DMA submissions, no workers.
 //
 // Who runs the pipelines.  A device has one staging context per NUMA node its callers' pages can be on (set 0: next to
 // the GPU); a context owns a pool of slots and a pool of PARKED worker threads (started on first use, bound to the
@@ -166,7 +164,10 @@ MODGPU_KNOB_STORAGE int kFeed = MODGPU_KNOB("MODGPU_HOST_FEED", 1, 0, 1);
 MODGPU_KNOB_STORAGE int kFileFeed = MODGPU_KNOB("MODGPU_HOST_FILE_FEED", 1, 0, 1);
 MODGPU_KNOB_STORAGE uint64_t kFeedChunk = (uint64_t)MODGPU_KNOB("MODGPU_HOST_FEED_CHUNK_KB", 256, 32, 8192) << 10;
 constexpr uint32_t kFeedChunksMax = 8192;      // ready / done words per call (larger calls take larger chunks)
-constexpr uint64_t kFeedBelow = 2ull << 30;    // from here up a launch per 8 MiB chunk is as good or better (4 GiB: 49.3 against 48.7 GB/s, profiles/r05_pcie_feed.txt)
+constexpr uint64_t kFeedBelow = 2ull << 30;    // from here up a launch per 8 MiB chunk is as good or better (4 GiB, pageable: 49.3 against 48.7 GB/s, profiles/r05_pcie_feed.txt;
+                                               // file -> pageable 46.4 / 47.0; file -> page-locked in place 46.8 against 43.7, profiles/r06_file_routes.txt)
+constexpr uint64_t kFeedInPlaceBelow = 512ull << 20; // file -> page-locked memory, in place: ahead at 64 / 392 MiB (42.2 / 43.3 against 38.3 / 41.2 GB/s), behind from 1 GiB up
+                                               // (44.2 / 45.0 / 43.7 against 45.0 / 47.1 / 46.8 at 1 / 2 / 4 GiB): profiles/r06_file_routes.txt
 constexpr uint32_t kFeedGrid = 32;             // workgroups of the host-fed kernel: what saturates the link (profiles/r05_pcie_persist.txt)
 MODGPU_KNOB_STORAGE uint64_t kFeedPatienceTicks = 1000000000ull; // 10 s of the 100 MHz wall clock: a chunk the host has not delivered by then never comes
 
@@ -1020,7 +1021,7 @@ RoutePlan plan_route(CallCtx &c)
         const uint64_t fc = std::max<uint64_t>((kFeedChunk + piece - 1) / piece * piece, ((n + kFeedChunksMax - 1) / kFeedChunksMax + piece - 1) / piece * piece);
         const int pipes_wanted = (int)std::min<uint64_t>((uint64_t)kPipes, ((n + fc - 1) / fc + 1) / 2);
         const uint64_t head = p.route == Route::in_dst ? (16 - (reinterpret_cast<uintptr_t>(dst.mem) & 15)) & 15 : 0;
-        if (fc <= kChunk && (n + piece - 1) / piece < kFeedPiecesMax && (n < kFeedBelow || p.route == Route::in_dst) && n > head + piece &&
+        if (fc <= kChunk && (n + piece - 1) / piece < kFeedPiecesMax && n < (p.route == Route::in_dst ? kFeedInPlaceBelow : kFeedBelow) && n > head + piece &&
             (pipes_wanted <= 1 || ensure_workers(c.s, pipes_wanted - 1, c.dev, physical_of(c.dev), c.caller_mask, c.have_mask) >= pipes_wanted - 1)) {
             p.chunk = fc;
             p.head = head;

@@ -20,7 +20,7 @@ fileroutes)
   cat $O/r06_file_routes.txt ;;
 pcie)
   [ -s $O/r06_pcie_ceiling.txt ] || tools/ubench_pcie_ceiling 1024 5 > $O/r06_pcie_ceiling.txt 2>&1
-  for spec in "pinned 1024 6" "staged 16 20" "staged 64 20" "staged 256 10" "staged 1024 6" "file_pageable 64 20" "file_pageable 392 10" "file_pinned 64 20" "file_pinned 392 10" "file_pinned 4096 4"; do
+  for spec in "pinned 1024 6" "staged 16 20" "staged 64 20" "staged 256 10" "staged 1024 6" "file_pageable 64 20" "file_pageable 392 10" "file_pinned 64 20" "file_pinned 392 10" "file_pinned 1024 6"; do
     set -- $spec
     D=$O/r06_pcie_$1_$2
     rm -rf $D
