@@ -309,8 +309,8 @@ def test_modgpu_prepare_for_callers_with_their_own_device_memory(gpu):
     THEM.  A caller with its own hipMalloc / hipMemcpy gets the same by name: modgpu_prepare(device), ABI 8.  Fresh processes (that is
     the point: a process's first launch), own upload of a 411 MB part after 1.5 s of idleness, ONE launch with its own pair of HIP
     events -- in the same harness for the three kinds of caller (median of three processes each): own upload + modgpu_prepare is
-    as good as uploading through the library's helpers (within 10 %), both are within 20 % of the size's STEADY rate (measured:
-    1.10-1.15 -- an event pair around a launch from an idle queue also holds the host's planning and packet write, ~12 us of a
+    as good as uploading through the library's helpers (within 15 %), both are within 30 % of the size's STEADY rate (measured:
+    1.06-1.15 -- an event pair around a launch from an idle queue also holds the host's planning and packet write, ~12 us of a
     0.126 ms launch: profiles/r05_first_launch.txt run F has the dispatch itself at 0.127), and without modgpu_prepare the same launch
     pays the code object and the ring (measured: 11.6 ms, 92 x)."""
     import json
@@ -329,9 +329,10 @@ def test_modgpu_prepare_for_callers_with_their_own_device_memory(gpu):
     lib = sorted(x["first_over_steady"] for x in via_library)[1]
     print("first launch / steady: own upload + modgpu_prepare", [x["first_over_steady"] for x in with_prepare], " via the library's helpers",
           [x["first_over_steady"] for x in via_library], " own upload alone:", without["first_over_steady"], without["first_launch"])
-    assert own <= 1.20 and lib <= 1.20, (with_prepare, via_library)
-    assert own <= 1.10 * lib, (own, lib)
-    assert without["first_over_steady"] > 2.0 * own  # (what the call is for)
+    # (bounds with room for another box's mood: measured 1.06-1.15 for both kinds, 74-92 x without)
+    assert own <= 1.30 and lib <= 1.30, (with_prepare, via_library)
+    assert own <= 1.15 * lib, (own, lib)
+    assert without["first_over_steady"] > 10.0 * own  # (what the call is for: the code object alone is ~10 ms)
     assert gpu.lib().modgpu_abi_version() == 8
 
 
