@@ -22,6 +22,7 @@ Rank 0 prints ONE JSON line.  `value` = part bytes cycled per second summed over
 import argparse
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -169,6 +170,18 @@ def launch_ranks(n_ranks, argv):
                    MASTER_PORT=str(port), MODGPU_BENCH_RDZV=f"tcp:127.0.0.1:{port}", MODGPU_BENCH_LAUNCHER="bench.py")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    def stop_ranks(signum, _frame):  # whoever stops this process (a time limit, ^C) stops the ranks it started -- by their PIDs
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10.0)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        os._exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, stop_ranks)
     rank0_out = []
     reader = threading.Thread(target=lambda: rank0_out.append(procs[0].stdout.read()), daemon=True)
     reader.start()

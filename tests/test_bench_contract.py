@@ -148,3 +148,31 @@ def test_bench_under_torchrun_meets_on_the_loopback_socket(modgpu):
     assert r.returncode != 0
     assert (r.stdout + r.stderr).count("no HIP device: bench.py measures the HIP path only") == 2, r.stdout[-2000:] + r.stderr[-2000:]
     assert "nobody listens" not in r.stderr and '"metric"' not in r.stdout
+
+
+def test_stopping_the_launcher_stops_its_ranks(tmp_path):
+    """`python bench.py --gpus N` is a parent of N rank processes: a time limit or ^C that ends the parent must not leave ranks behind on
+    the GPUs.  The ranks here are stand-ins that sleep (bench.launch_ranks starts `sys.executable bench.py ...`; the test points it at a
+    sleeper through the module's own __file__), the parent gets SIGTERM, both ranks are gone within seconds and the parent exits 128 + 15."""
+    import signal
+    import time
+    sleeper = tmp_path / "bench.py"
+    sleeper.write_text("import os, sys, time\nopen(sys.argv[1] + '/pid.' + os.environ['RANK'], 'w').write(str(os.getpid()))\ntime.sleep(120)\n")
+    code = ("import sys, bench\n"
+            f"bench.__file__ = {str(sleeper)!r}\n"
+            f"raise SystemExit(bench.launch_ranks(2, [{str(tmp_path)!r}]))\n")
+    p = subprocess.Popen([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT))
+    deadline = time.time() + 30
+    while time.time() < deadline and not all((tmp_path / f"pid.{r}").exists() and (tmp_path / f"pid.{r}").read_text() for r in (0, 1)):
+        time.sleep(0.05)
+    pids = [int((tmp_path / f"pid.{r}").read_text()) for r in (0, 1)]
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    time.sleep(0.2)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = open(f"/proc/{pid}/stat").read().split()[2] != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, pid
