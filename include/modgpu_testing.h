@@ -155,8 +155,8 @@ enum { MODGPU_TUNABLE_ZEROCOPY_BYTES = 0, MODGPU_TUNABLE_RING = 1, MODGPU_TUNABL
        MODGPU_TUNABLE_FEED = 8,       /* 1 (the shipped rule): pageable memory on both sides is cycled by ONE host-fed kernel per call; 0: a launch per chunk */
        MODGPU_TUNABLE_FEED_CHUNK_BYTES = 9, /* chunk of a host-fed call (256 KiB; whole 32 KiB pieces) */
        MODGPU_TUNABLE_FEED_PATIENCE_MS = 10, /* how long the host-fed kernel waits for one chunk before it gives the call up (10 000) */
-       MODGPU_TUNABLE_FILE_FEED = 11 /* 1 (the shipped rule): a FILE that ends in memory takes the host-fed kernel too -- through the slots into
-                                        pageable memory, in place into page-locked memory; 0: round 5's launch per chunk */ };
+       MODGPU_TUNABLE_FILE_FEED = 11 /* 1 (the shipped rule): a FILE that ends in memory (pageable, or page-locked below 2 GiB) takes the host-fed
+                                        kernel too, pread in place of the copy into the slot; 0: round 5's launch per chunk */ };
 void modgpu_debug_set_host_tunable(int which, uint64_t value);
 
 /* The NUMA node the library believes its GPUs hang off (-1 = unknown, -2 = ask sysfs, the default).  Lets a one-node machine

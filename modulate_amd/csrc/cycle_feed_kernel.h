@@ -25,8 +25,7 @@ constexpr int kFeedSlotsMax = 32;             // 16 pipelines x 2 slots
 constexpr uint32_t kFeedPieceBytes = 32768u;  // a ticket: 8 trips of 256 lanes x 16 bytes
 constexpr uint32_t kFeedPiecesMax = 1u << 24; // the three-byte jump tables: 512 GiB per call
 struct CycleFeedArgs {
-    uint8_t *slot[kFeedSlotsMax]; // the call's slots as the device addresses them: chunk k is in slot[(k % pipes) * 2 + (k / pipes) % 2];
-                                  // pipes == 0: slot[0] is the 16-byte-aligned start of the whole stream, chunk k lies at slot[0] + k * chunk_bytes
+    uint8_t *slot[kFeedSlotsMax]; // the call's slots as the device addresses them: chunk k is in slot[(k % pipes) * 2 + (k / pipes) % 2]
     const uint32_t *ready;        // [chunks] host memory, written by the host: chunk k has been copied into its slot
     const uint32_t *abort;        // host memory: the call is lost, leave
     uint32_t *done;               // [chunks] host memory, written by the kernel: chunk k's slot holds the result
@@ -34,10 +33,8 @@ struct CycleFeedArgs {
     uint64_t n;                   // bytes of the call (the last piece may be short and need not end on a 16-byte word)
     uint64_t patience_ticks;      // longest wait for one chunk, in ticks of the 100 MHz wall clock
     uint32_t chunk_bytes;         // a multiple of kFeedPieceBytes, at most the slot size
-    uint32_t pipes;               // pipelines of the call (each owns two slots); 0 = in place, no slots
-    uint32_t base;                // canonical state of the stream's first byte (the byte at slot[0] when pipes == 0)
-    uint32_t head;                // pipes == 0 only: bytes (< 16) in front of slot[0] that belong to the call; they are cycled with ticket 0
-    uint32_t base_head;           // ... and the canonical state of the first of them
+    uint32_t pipes;               // pipelines of the call (each owns two slots)
+    uint32_t base;                // canonical state of the call's first byte
 };
 uint32_t modgpu_feed_block();
 const char *modgpu_feed_kernel_name();

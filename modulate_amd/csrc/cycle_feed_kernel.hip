@@ -70,9 +70,7 @@ __global__ __launch_bounds__(256) void modgpu_cycle_feed_kernel(CycleFeedArgs a)
         }
         const uint32_t c = t / tpc, piece = t - c * tpc;
         const uint64_t pos = (uint64_t)t * kFeedPieceBytes; // stream position of the piece's first byte
-        // where the piece lies: in its chunk's staging slot -- or, with pipes == 0, in place: the whole stream is contiguous at slot[0]
-        // (file -> page-locked destination: the host reads each chunk to where it belongs and the kernel cycles it there)
-        uint8_t *const p = a.pipes ? a.slot[(c % a.pipes) * 2u + (c / a.pipes) % 2u] + (uint64_t)piece * kFeedPieceBytes : a.slot[0] + pos;
+        uint8_t *const p = a.slot[(c % a.pipes) * 2u + (c / a.pipes) % 2u] + (uint64_t)piece * kFeedPieceBytes; // the piece in its chunk's staging slot
         const uint32_t len = (uint32_t)(a.n - pos < kFeedPieceBytes ? a.n - pos : kFeedPieceBytes);
         const uint32_t words = len / lcg::WORD;
         // state of the piece's first byte: base * a^(32768 * t), by the three bytes of t
@@ -97,13 +95,6 @@ __global__ __launch_bounds__(256) void modgpu_cycle_feed_kernel(CycleFeedArgs a)
             st = mulmod_canon(st, c_tile_lo.v[words >> 8]);
             for (uint32_t k = 0; k < tid; ++k) st = mulmod_canon(st, lcg::A);
             uint8_t *const q = p + words * lcg::WORD + tid;
-            *q = cycle_byte(*q, st);
-        }
-        // (in place only) the < 16 bytes in front of the stream's first 16-byte boundary, with the first ticket
-        if (t == 0 && tid < a.head) {
-            uint32_t st = a.base_head;
-            for (uint32_t k = 0; k < tid; ++k) st = mulmod_canon(st, lcg::A);
-            uint8_t *const q = a.slot[0] - a.head + tid;
             *q = cycle_byte(*q, st);
         }
         __threadfence_system(); // this wave's stores have reached host memory ...

@@ -11,14 +11,14 @@
 //   one slot          <= 1 MiB, what the reference's three call sites pass (headers): one slot, one kernel across PCIe, no workers.
 //   pipelined         everything else, cut into pieces for up to kPipes pipelines (host thread + two slots each) on one of five ROUTES
 //                     (enum Route; each a submit / wait pair over the shared core run_route):
-//                       feed         pageable memory, or a part file, that ends in pageable memory: copy / pread -> pinned slot -> the
-//                                    call's ONE host-fed kernel (cycle_feed_kernel.h) cycles the slot across PCIe -> copy out.  256 KiB
-//                                    chunks; a pipeline marks its chunk ready in page-locked memory and polls the chunk's done word.
-//                       feed_in_dst  a part file that ends in page-locked memory: pread lands in the destination, the one kernel
-//                                    cycles it there -- no slot, no copy.
-//                       slot_kernel  the same as feed with a LAUNCH PER CHUNK (~64 pieces of >= 1 MiB behind a 512 KiB ramp, kernels on
-//                                    4 shared lanes): calls of 2 GiB and more, memory -> file, file -> file, a set without worker threads.
-//                       in_dst       feed_in_dst with a launch per chunk (testing flavour: file_feed = 0).
+//                       feed         pageable memory, or a part file, that ends in memory (pageable or page-locked), below 2 GiB:
+//                                    copy / pread -> pinned slot -> the call's ONE host-fed kernel (cycle_feed_kernel.h) cycles the slot
+//                                    across PCIe -> copy out.  256 KiB chunks; a pipeline marks its chunk ready in page-locked memory
+//                                    and polls the chunk's done word.
+//                       slot_kernel  the same with a LAUNCH PER CHUNK (~64 pieces of >= 1 MiB behind a 512 KiB ramp, kernels on 4 shared
+//                                    lanes): calls of 2 GiB and more, memory -> file, file -> file, a set without worker threads.
+//                       in_dst       a part file of 2 GiB or more that ends in page-locked memory: pread lands in the destination, a
+//                                    launch per chunk cycles it where it lies -- no slot, no copy.
 //                       dma          page-locked memory that is not cycled in place (e.g. -> file): H2D DMA -> kernel in HBM -> D2H DMA.
 //                     A file endpoint replaces its copy by pread / pwrite on the pinned slot.
 //
@@ -158,16 +158,15 @@ MODGPU_KNOB_STORAGE int kFileSched = MODGPU_KNOB("MODGPU_HOST_FILE_SCHED", 1, 0,
 // uniform chunks of feed_chunk bytes (no ramp needed: nothing is launched per chunk), marked ready / done through words in page-locked
 // memory.  profiles/r05_pcie_feed.txt.  0 (and staged mode 2 of the testing flavour): the launch-per-chunk schedule above.
 MODGPU_KNOB_STORAGE int kFeed = MODGPU_KNOB("MODGPU_HOST_FEED", 1, 0, 1);
-// file_feed: a FILE that ends in memory takes the host-fed kernel too (round 6): into pageable memory pread replaces the copy into the
-// slot; into page-locked memory the chunks are read to where they belong and the one kernel cycles them there (no slot, no copy).
-// 0 (testing flavour): round 5's launch per chunk.  profiles/r06_file_routes.txt.
+// file_feed: a FILE that ends in memory takes the host-fed kernel too (round 6): pread replaces the copy into the slot -- into pageable
+// memory and, below 2 GiB, into page-locked memory as well (three ways were measured for that destination, profiles/r06_file_routes.txt:
+// through the slots 43.5 / 47.0 / 47.3 GB/s at 64 / 392 / 1024 MiB, one host-fed kernel working in the destination itself 42.3 / 44.2 /
+// 44.4, round 5's launch per chunk in the destination 38.8 / 43.8 / 46.1).  0 (testing flavour): round 5's launch per chunk.
 MODGPU_KNOB_STORAGE int kFileFeed = MODGPU_KNOB("MODGPU_HOST_FILE_FEED", 1, 0, 1);
 MODGPU_KNOB_STORAGE uint64_t kFeedChunk = (uint64_t)MODGPU_KNOB("MODGPU_HOST_FEED_CHUNK_KB", 256, 32, 8192) << 10;
 constexpr uint32_t kFeedChunksMax = 8192;      // ready / done words per call (larger calls take larger chunks)
 constexpr uint64_t kFeedBelow = 2ull << 30;    // from here up a launch per 8 MiB chunk is as good or better (4 GiB, pageable: 49.3 against 48.7 GB/s, profiles/r05_pcie_feed.txt;
-                                               // file -> pageable 46.4 / 47.0; file -> page-locked in place 46.8 against 43.7, profiles/r06_file_routes.txt)
-constexpr uint64_t kFeedInPlaceBelow = 512ull << 20; // file -> page-locked memory, in place: ahead at 64 / 392 MiB (42.2 / 43.3 against 38.3 / 41.2 GB/s), behind from 1 GiB up
-                                               // (44.2 / 45.0 / 43.7 against 45.0 / 47.1 / 46.8 at 1 / 2 / 4 GiB): profiles/r06_file_routes.txt
+                                               // file -> pageable 46.4 / 47.0, profiles/r06_file_routes.txt)
 constexpr uint32_t kFeedGrid = 32;             // workgroups of the host-fed kernel: what saturates the link (profiles/r05_pcie_persist.txt)
 MODGPU_KNOB_STORAGE uint64_t kFeedPatienceTicks = 1000000000ull; // 10 s of the 100 MHz wall clock: a chunk the host has not delivered by then never comes
 
@@ -428,7 +427,6 @@ enum class Route {
     in_dst,       // file -> page-locked caller memory: pread lands in the destination itself, a launch per chunk cycles it where it lies
     feed,         // as slot_kernel, but ONE host-fed kernel for the whole call (cycle_feed_kernel.h): a pipeline marks its chunk ready
                   // in page-locked memory and polls the chunk's done word
-    feed_in_dst,  // as in_dst, with the one host-fed kernel working in the destination (no slot, no copy, no launch per chunk)
 };
 
 // What a call knows about each piece of its stream.  The cipher is positional and the pieces are disjoint, so a call that loses
@@ -454,9 +452,9 @@ struct Job {
     cpu_set_t caller_mask; // the calling thread's affinity mask: a worker is never put on a CPU the caller may not use
     bool have_mask = false;
     Job(const Endpoint &s, const Endpoint &d, uint64_t n_, uint64_t chunk_, int32_t key_, uint64_t off_) : src(s), dst(d), n(n_), chunk(chunk_), key(key_), stream_off(off_) {}
-    bool fed() const { return route == Route::feed || route == Route::feed_in_dst; }
+    bool fed() const { return route == Route::feed; }
     // the device writes the caller's destination itself (DMA or a kernel in place): an unfinished piece of it is undefined
-    bool dst_written_by_device() const { return (dst.mem && dst.pinned) || route == Route::in_dst || route == Route::feed_in_dst; }
+    bool dst_written_by_device() const { return route == Route::in_dst || (route == Route::dma && dst.mem && dst.pinned); }
     void set_plan(std::vector<Piece> p)
     {
         plan = std::move(p);
@@ -468,21 +466,15 @@ struct Job {
 // Cuts [0, n) into pieces of `chunk` bytes for `pipes` pipelines.  With a ramp the first and the last `pipes` pieces -- every
 // pipeline's first and last -- are only `ramp` bytes: the link carries nothing while the first pieces are copied into their slots
 // and nothing while the last are copied out, and that exposed time shrinks with them (profiles/r04_staged_midsize.txt).
-// `head` bytes in front of the first piece belong to it (feed_in_dst: the kernel's chunks are counted from the destination's first
-// 16-byte boundary, the < 16 bytes in front of it travel with chunk 0).
-std::vector<Piece> cut_stream(uint64_t n, uint64_t chunk, int pipes, uint64_t ramp, uint64_t head = 0)
+std::vector<Piece> cut_stream(uint64_t n, uint64_t chunk, int pipes, uint64_t ramp)
 {
     std::vector<Piece> plan;
     uint64_t at = 0;
     const uint64_t edge = (uint64_t)pipes * ramp;
-    const bool ramped = ramp > 0 && ramp < chunk && pipes > 1 && n >= 2 * edge + (uint64_t)pipes * chunk && head == 0;
+    const bool ramped = ramp > 0 && ramp < chunk && pipes > 1 && n >= 2 * edge + (uint64_t)pipes * chunk;
     if (ramped)
         for (int p = 0; p < pipes; ++p, at += ramp) plan.push_back({at, ramp});
     const uint64_t middle_end = ramped ? n - edge : n;
-    if (head && at < middle_end) {
-        plan.push_back({0, std::min<uint64_t>(head + chunk, middle_end)});
-        at = plan.back().len;
-    }
     for (; at < middle_end; at += chunk) plan.push_back({at, std::min<uint64_t>(chunk, middle_end - at)});
     if (ramped)
         for (at = middle_end; at < n; at += ramp) plan.push_back({at, std::min<uint64_t>(ramp, n - at)});
@@ -523,7 +515,7 @@ int feed_wait(Job &j, uint64_t c)
 // rescue rests on: on the routes that pass through a slot (dma with a pageable destination, slot_kernel, feed) a piece changes
 // the caller's destination in exactly one place -- drain_slot in retire() below, after the piece's wait has succeeded -- and
 // j.touched is raised right in front of it; the routes on which the DEVICE writes the destination (dma into page-locked memory,
-// in_dst, feed_in_dst: Job::dst_written_by_device) raise it in their submit.
+// in_dst: Job::dst_written_by_device) raise it in their submit.
 struct Pipe {
     Staging &s;
     const int *slots;
@@ -669,25 +661,6 @@ struct RouteFeed { // the kernel is there already, waiting for exactly this chun
     }
     static int wait(Pipe &p, uint64_t c, int) { return feed_wait(p.j, c); }
 };
-struct RouteFeedInDst { // ... and works where the chunk was read to: the caller's page-locked destination
-    static bool drains(const Pipe &) { return false; }
-    static int submit(Pipe &p, uint64_t c, int)
-    {
-        Job &j = p.j;
-        const uint64_t off = j.plan[c].off, len = j.plan[c].len;
-        stall_until_the_kernel_has_left(p, c);
-        j.touched.store(true, std::memory_order_relaxed);
-        int rc = fill_slot(j.src, j.dst.mem + off, off, len);
-        if (rc) return rc;
-        trace(MODGPU_TRACE_FILL_END, p.pipe, c, len);
-        MODGPU_INJECT(p, c, MODGPU_STAGE_LAUNCH);
-        __atomic_store_n(&j.feed_ready[c], 1u, __ATOMIC_RELEASE);
-        trace(MODGPU_TRACE_READY, p.pipe, c, len);
-        return MODGPU_OK;
-    }
-    static int wait(Pipe &p, uint64_t c, int) { return feed_wait(p.j, c); }
-};
-
 // -- the core every route runs on: step i retires the chunk that used this step's slot `ring` steps ago, then submits chunk i
 template <class R> int retire(Pipe &p, uint64_t c, int slot)
 {
@@ -745,7 +718,6 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
     case Route::slot_kernel: rc = run_route<RouteSlotKernel>(p); break;
     case Route::in_dst: rc = run_route<RouteInDst>(p); break;
     case Route::feed: rc = run_route<RouteFeed>(p); break;
-    case Route::feed_in_dst: rc = run_route<RouteFeedInDst>(p); break;
     }
     if (rc != MODGPU_OK) { // nothing of this call may still be running against the caller's memory (or its slots) once we return
         if (rc != kStopped) j.failed.store(true, std::memory_order_release);
@@ -919,11 +891,12 @@ struct CallCtx {
     cpu_set_t caller_mask;
     bool have_mask = false;
     StreamOutcome &outcome;
+    bool through_slots = false; // the bytes pass through a page-locked slot with a host copy on a memory side (modgpu_path_stats: staged_bytes)
     void account(uint64_t host_bytes = 0) const
     {
         g_stats.gpu_calls.fetch_add(1, std::memory_order_relaxed);
         g_stats.gpu_bytes.fetch_add(n - host_bytes, std::memory_order_relaxed);
-        (all_direct ? g_stats.direct_bytes : g_stats.staged_bytes).fetch_add(n - host_bytes, std::memory_order_relaxed);
+        (all_direct && !through_slots ? g_stats.direct_bytes : g_stats.staged_bytes).fetch_add(n - host_bytes, std::memory_order_relaxed);
     }
 };
 int injected_here() { return fail(MODGPU_ERR_HIP, "injected failure (modgpu_debug_inject_failure_at)"); }
@@ -983,11 +956,10 @@ int one_slot_call(CallCtx &c)
     return MODGPU_OK;
 }
 
-// Which route a pipelined call takes, the size of its pieces, and (feed_in_dst) how many bytes lie in front of the destination's
-// first 16-byte boundary.
+// Which route a pipelined call takes and the size of its pieces.
 struct RoutePlan {
     Route route;
-    uint64_t chunk, head;
+    uint64_t chunk;
     bool memory_schedule; // cut and queued like a memory-to-memory call: ~64 chunks of >= 1 MiB, ramped, kernels on shared lanes
 };
 RoutePlan plan_route(CallCtx &c)
@@ -1007,26 +979,28 @@ RoutePlan plan_route(CallCtx &c)
     // slot and cycled there across PCIe; a file that ends in page-locked caller memory is read straight into that memory and cycled
     // where it lies; page-locked caller memory that ends in a file is DMA'd.  (Testing flavour, staged mode 1: the DMA form -- H2D,
     // kernel in HBM, D2H -- of the first two.)
-    p.route = c.dst_direct && !src.mem && !c.identity && staged_mode() != 1 ? Route::in_dst
-              : !c.src_direct && !c.dst_direct && staged_mode() != 1        ? Route::slot_kernel
-                                                                            : Route::dma;
+    // A part file that ends in page-locked memory: below 2 GiB through the slots like any other destination (the host-fed kernel wins
+    // there); from 2 GiB up -- or with file_feed off -- read straight into that memory and cycled where it lies, a launch per chunk.
+    const bool file_to_locked_pages = c.dst_direct && !src.mem && !c.identity && staged_mode() != 1;
+    const bool through_slots = file_to_locked_pages && kFeed != 0 && kFileFeed != 0 && staged_mode() == 0 && n < kFeedBelow;
+    p.route = file_to_locked_pages && !through_slots                               ? Route::in_dst
+              : !c.src_direct && (!c.dst_direct || through_slots) && staged_mode() != 1 ? Route::slot_kernel
+                                                                                       : Route::dma;
     // A pageable (or file) source that ends in memory: ONE host-fed kernel for the whole call (cycle_feed_kernel.h) instead of a launch
     // per chunk.  Uniform chunks -- as small as the flag words allow, since no chunk costs a launch -- of whole pieces; a call too large
     // for that (or staged mode 1 / 2 of the testing flavour, or feed switched off) keeps the launch-per-chunk schedule.  The kernel draws
     // chunks in stream order and waits for whichever pipeline owns the next one, so the pipelines must really run side by side: a
-    // staging set that cannot have its worker threads does not take these routes.
+    // staging set that cannot have its worker threads does not take this route.
     const bool feedable = kFeed != 0 && staged_mode() == 0 && !c.identity && dst.mem && (src.mem ? !c.src_direct && !c.dst_direct : kFileFeed != 0);
-    if (feedable && (p.route == Route::slot_kernel || p.route == Route::in_dst)) {
+    if (feedable && p.route == Route::slot_kernel) {
         const uint64_t piece = kFeedPieceBytes;
         const uint64_t fc = std::max<uint64_t>((kFeedChunk + piece - 1) / piece * piece, ((n + kFeedChunksMax - 1) / kFeedChunksMax + piece - 1) / piece * piece);
         const int pipes_wanted = (int)std::min<uint64_t>((uint64_t)kPipes, ((n + fc - 1) / fc + 1) / 2);
-        const uint64_t head = p.route == Route::in_dst ? (16 - (reinterpret_cast<uintptr_t>(dst.mem) & 15)) & 15 : 0;
-        if (fc <= kChunk && (n + piece - 1) / piece < kFeedPiecesMax && n < (p.route == Route::in_dst ? kFeedInPlaceBelow : kFeedBelow) && n > head + piece &&
+        if (fc <= kChunk && (n + piece - 1) / piece < kFeedPiecesMax && n < kFeedBelow &&
             (pipes_wanted <= 1 || ensure_workers(c.s, pipes_wanted - 1, c.dev, physical_of(c.dev), c.caller_mask, c.have_mask) >= pipes_wanted - 1)) {
             p.chunk = fc;
-            p.head = head;
-            p.route = p.route == Route::in_dst ? Route::feed_in_dst : Route::feed;
-        }
+            p.route = Route::feed;
+        } else if (through_slots) p.route = Route::in_dst; // (no host-fed kernel to be had: the destination itself, as from 2 GiB up)
     }
     return p;
 }
@@ -1065,22 +1039,16 @@ struct FeedCall {
     {
         Staging &s = c.s;
         CycleFeedArgs a{};
-        if (plan.route == Route::feed_in_dst) { // the chunks are read to where they belong: the kernel's stream starts at the destination's first 16-byte boundary
-            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&a.slot[0]), c.dst.mem, 0));
-            a.slot[0] += plan.head;
-        } else
-            for (int k = 0; k < pipes * 2; ++k) HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&a.slot[k]), s.pinned[slots[(size_t)k]], 0));
+        for (int k = 0; k < pipes * 2; ++k) HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&a.slot[k]), s.pinned[slots[(size_t)k]], 0));
         a.ready = s.feed_flags_dev[lead_slot];
         a.done = s.feed_flags_dev[lead_slot] + kFeedChunksMax;
         a.abort = s.feed_flags_dev[lead_slot] + 2 * kFeedChunksMax;
         a.work = s.feed_work[lead_slot]; // (all zero: feed_reserve, finish)
-        a.n = c.n - plan.head;
+        a.n = c.n;
         a.patience_ticks = kFeedPatienceTicks;
         a.chunk_bytes = (uint32_t)plan.chunk;
-        a.pipes = plan.route == Route::feed_in_dst ? 0u : (uint32_t)pipes;
-        a.head = (uint32_t)plan.head;
-        a.base_head = lcg::state_residue(lcg::key_residue(c.key), c.stream_off);
-        a.base = lcg::state_residue(lcg::key_residue(c.key), c.stream_off + plan.head);
+        a.pipes = (uint32_t)pipes;
+        a.base = lcg::state_residue(lcg::key_residue(c.key), c.stream_off);
         const uint32_t pieces = (uint32_t)((a.n + kFeedPieceBytes - 1) / kFeedPieceBytes);
         const uint32_t grid = std::min<uint32_t>(kFeedGrid, pieces);
         const hipError_t e = modgpu_launch_cycle_feed(a, grid, job.feed_stream);
@@ -1141,10 +1109,11 @@ int pipelined_call(CallCtx &c)
 {
     Staging &s = c.s;
     const RoutePlan plan = plan_route(c);
-    const bool feed = plan.route == Route::feed || plan.route == Route::feed_in_dst;
-    const uint64_t n_chunks = (c.n - plan.head + plan.chunk - 1) / plan.chunk;
+    const bool feed = plan.route == Route::feed;
+    const uint64_t n_chunks = (c.n + plan.chunk - 1) / plan.chunk;
     Job job(c.src, c.dst, c.n, plan.chunk, c.key, c.stream_off);
     job.route = plan.route;
+    c.through_slots = plan.route == Route::feed || plan.route == Route::slot_kernel;
     int pipes, ring;
     if (c.all_direct && c.src.mem && c.dst.mem) { // no host work at all: one thread keeps a ring of slots busy
         pipes = 1;
@@ -1161,14 +1130,13 @@ int pipelined_call(CallCtx &c)
     SlotLease lease(s);
     lease.acquire(pipes * ring, ring);
     pipes = (int)lease.ids.size() / ring;
-    job.set_plan(cut_stream(c.n, plan.chunk, pipes, plan.memory_schedule && !feed ? kRamp : 0, plan.head));
+    job.set_plan(cut_stream(c.n, plan.chunk, pipes, plan.memory_schedule && !feed ? kRamp : 0));
     job.copy_node = c.copy_node;
     job.have_mask = c.have_mask;
     if (c.have_mask) job.caller_mask = c.caller_mask;
     for (int k = 0; k < (feed ? 0 : plan.memory_schedule ? kLanes : kFileLanes) && k < (int)lease.ids.size(); ++k) job.lanes.push_back(nullptr); // (streams exist after staging_reserve)
     trace(MODGPU_TRACE_SLOTS, -1, (uint64_t)pipes, plan.chunk);
-    const bool works_in_dst = plan.route == Route::in_dst || plan.route == Route::feed_in_dst;
-    int rc = staging_reserve(s, lease.ids, plan.chunk, plan.route == Route::dma, !(c.src_direct && c.dst_direct) && !works_in_dst);
+    int rc = staging_reserve(s, lease.ids, plan.chunk, plan.route == Route::dma, !(c.src_direct && c.dst_direct) && plan.route != Route::in_dst);
     if (rc) return rc;
     for (size_t k = 0; k < job.lanes.size(); ++k) job.lanes[k] = s.stream[lease.ids[k]];
     FeedCall fed{c, job, lease.ids, plan};

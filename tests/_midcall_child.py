@@ -176,16 +176,16 @@ if not strict and not only_stall:
     path = os.path.join(d, "midcall_%d.part" % os.getpid())
     pt.tofile(path)
     try:
-        # Since round 6 both take the host-fed kernel (one launch per call): into pageable memory through the slots (pread replaces the
-        # copy in), into page-locked memory IN PLACE (the chunks are read to where they belong; `shift` misaligns the destination so
-        # that the < 16 bytes in front of its first 16-byte boundary travel with chunk 0).  file_feed = 0: round 5's launch per chunk.
+        # Since round 6 both take the host-fed kernel (one launch per call), pread in place of the copy into the slot -- into pageable
+        # memory and (below 2 GiB) into page-locked memory alike; `shift` misaligns the page-locked destination.  file_feed = 0: round 5's
+        # launch per chunk, which for a page-locked destination works IN the destination (nothing is copied out: no DRAIN stage there).
         for file_feed in (1, 0):
             M.debug_set_host_tunable("file_feed", file_feed)
             for pinned_dst, shift in ((False, 0), (True, 0), (True, 5)):
                 for piece, stage in ((0, M.STAGE_FILL), (M.INJECT_PIECE_MIDDLE, M.STAGE_SYNC), (M.INJECT_PIECE_LAST, M.STAGE_LAUNCH), (M.INJECT_PIECE_MIDDLE, M.STAGE_AFTER_DRAIN),
                                      (M.INJECT_PIECE_LAST, M.STAGE_DRAIN), (0, M.STAGE_SYNC)) + (((M.INJECT_PIECE_MIDDLE, M.STAGE_STALL),) if file_feed else ()):
-                    if stage == M.STAGE_DRAIN and pinned_dst:
-                        continue  # (nothing is copied out on the in-place routes: the stage does not exist there)
+                    if stage == M.STAGE_DRAIN and pinned_dst and not file_feed:
+                        continue
                     if pinned_dst:
                         pb = M.PinnedBuffer(n + 16)
                         pb.array[:] = 0

@@ -119,8 +119,7 @@ void run_feed(void *arg)
         }
         if (gave_up) break;
         const uint64_t pos = c * a->chunk_bytes, len = std::min<uint64_t>(a->chunk_bytes, a->n - pos);
-        uint8_t *slot = a->pipes ? a->slot[(c % a->pipes) * 2 + (c / a->pipes) % 2] : a->slot[0] + pos; // pipes == 0: in place, contiguous
-        if (c == 0 && a->pipes == 0 && a->head) span(a->slot[0] - a->head, a->head, a->base_head);
+        uint8_t *slot = a->slot[(c % a->pipes) * 2 + (c / a->pipes) % 2];
         span(slot, len, lcg::mulmod(a->base, lcg::powmod(lcg::A, pos % lcg::PERIOD)));
         std::atomic_ref<uint32_t>(a->done[c]).store(1u, std::memory_order_release);
     }

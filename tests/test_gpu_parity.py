@@ -255,12 +255,11 @@ def test_host_fed_kernel_route(gpu_t, oracle):
 
 def test_file_to_memory_takes_the_host_fed_kernel(gpu_t, oracle, tmp_path):
     """VERDICT r5 #3 (LoadArkData's part cipher, Modulate/CArk.cpp:741-755): a part FILE that ends in memory is cycled by ONE host-fed
-    launch per call.  Into pageable memory pread replaces the copy into the slot; into page-locked memory the chunks are read to where
-    they belong and the kernel cycles them IN PLACE -- counted from the destination's first 16-byte boundary, the bytes in front of it
-    travel with chunk 0, so every misalignment 0..15 is a case.  Ragged sizes (a short last piece, a tail that is no whole word, a call
-    of one or two chunks), file windows with their own stream offset, 32 KiB .. 1 MiB chunks; whole buffers incl. guard bytes; exactly
-    one launch per call, and it is the host-fed kernel with its TU's own source hash; file_feed = 0 gives round 5's launch per chunk
-    and the same bytes."""
+    launch per call, pread in place of the copy into the slot -- into pageable memory and into page-locked memory alike (for the
+    latter three ways were measured, profiles/r06_file_routes.txt; through the slots won).  Ragged sizes (a short last piece, a tail
+    that is no whole word, a call of one or two chunks), file windows with their own stream offset, 32 KiB .. 1 MiB chunks, every
+    misalignment 0..15 of the destination; whole buffers incl. guard bytes; exactly one launch per call, and it is the host-fed kernel
+    with its TU's own source hash; file_feed = 0 gives round 5's launch per chunk and the same bytes."""
     gpu = gpu_t
     sizes = [(1 << 20) + 1, (1 << 20) + 32768 + 17, (2 << 20) + 4097, (3 << 20) - 1, (9 << 20) + 15, (33 << 20) + 32767]
     big = oracle.splitmix_bytes(max(sizes) + 70_001, 606)
@@ -282,7 +281,7 @@ def test_file_to_memory_takes_the_host_fed_kernel(gpu_t, oracle, tmp_path):
                 assert ll["kernel"] == "modgpu_cycle_feed_kernel" and ll["variant"] == 4 and ll["source_hash"] == gpu.feed_kernel_source_hash(), ll
                 assert gpu.path_stats()["gpu_launches"] == before + 1
                 assert np.array_equal(out[9:9 + n], want) and np.all(out[:9] == 0xEE) and np.all(out[9 + n:] == 0xEE), (chunk, n, "pageable")
-                # -> page-locked memory, in place, at every misalignment for the smallest size and a few for the others
+                # -> page-locked memory, at every misalignment for the smallest size and a few for the others
                 for shift in (range(16) if k == 0 and chunk == (256 << 10) else (0, 5 + k, 15)):
                     pb.array[:] = 0xEE
                     before = gpu.path_stats()["gpu_launches"]
@@ -1059,8 +1058,10 @@ def test_host_register_pins_caller_memory_in_place(gpu, oracle):
 
 
 def test_pinned_endpoints_of_file_streams(gpu, oracle, tmp_path):
-    """CArk's part buffer is page-locked: file -> GPU -> pinned memory and pinned memory -> GPU -> file skip
-    the memory-side copy (what LoadArkData / SaveArk do with the part cipher on, CArk.cpp:751, 883)."""
+    """CArk's part buffer is page-locked (what LoadArkData / SaveArk do with the part cipher on, CArk.cpp:751, 883): pinned memory ->
+    GPU -> file skips the memory-side copy (DMA straight from the pages: direct_bytes); file -> GPU -> pinned memory goes through the
+    staging slots and the call's one host-fed kernel since round 6 (measured faster than working in the destination, below 2 GiB:
+    staged_bytes)."""
     n = (37 << 20) + 11
     pt = oracle.splitmix_bytes(n, 3)
     want = oracle.cycle(pt.copy(), oracle.KEY_PS4)
@@ -1074,7 +1075,7 @@ def test_pinned_endpoints_of_file_streams(gpu, oracle, tmp_path):
     assert np.array_equal(np.fromfile(tmp_path / "back.ark", dtype=np.uint8), pt)
     assert np.array_equal(pb.array[16:16 + n], want)  # the source is not modified
     after = gpu.path_stats()
-    assert after["direct_bytes"] == before["direct_bytes"] + 2 * n and after["staged_bytes"] == before["staged_bytes"]
+    assert after["direct_bytes"] == before["direct_bytes"] + n and after["staged_bytes"] == before["staged_bytes"] + n
     pb.free()
 
 
