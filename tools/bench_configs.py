@@ -83,29 +83,31 @@ def main():
     res["host_path_pinned"] = hpp
     if "host" in sections:
         # The roofline of everything above: host-resident data is bound by the PCIe link, which every byte crosses once in each
-        # direction.  peak = what this node's link carries in both directions at once, measured here by the DMA
-        # engines (tools/ubench_pcie_bidir) and by the best the kernel itself has been seen to do in place on page-locked memory
-        # (the kernel beats the DMA engines at this); beside it the spec of PCIe gen 5 x16.
-        import re
+        # direction.  Priced against figures this code did not produce: PCIe gen 5 x16 on paper, and the DMA engines of
+        # the same run (tools/ubench_pcie_ceiling: one way, both ways at once).
         import subprocess
-        dma = None
+        ceil = {}
         try:
-            out = subprocess.run([os.path.join(ROOT, "tools", "ubench_pcie_bidir")], capture_output=True, text=True, timeout=120).stdout
-            m = re.search(r"both ways:\s+([0-9.]+) GB/s", out)
-            dma = float(m.group(1)) if m else None
-            one_way = [float(x) for x in re.findall(r"only\s*:\s+([0-9.]+) GB/s", out)]
-        except (OSError, subprocess.SubprocessError):
-            one_way = []
-        kernel_peak = max(v["GBps_payload"] for v in hpp.values())
-        peak = max(kernel_peak, dma or 0.0)
+            out = subprocess.run([os.path.join(ROOT, "tools", "ubench_pcie_ceiling"), "1024", "3"], capture_output=True, text=True, timeout=300).stdout
+            ceil = json.loads([ln for ln in out.splitlines() if ln.startswith("CEILING ")][-1][len("CEILING "):])
+        except (OSError, subprocess.SubprocessError, IndexError, ValueError):
+            pass
+        link = float(ceil.get("peak_link", 64.0))
+        one_way = min(ceil["dma_h2d"], ceil["dma_d2h"]) if ceil else None
+        duplex = ceil.get("dma_duplex_per_direction")
+
+        def fracs(table, of):
+            return {k: round(v["GBps_payload"] / of, 4) for k, v in table.items() if int(k) >= (1 << 20)} if of else None
         res["roofline_pcie"] = {
             "bound": "pcie", "unit": "GB/s of payload = GB/s in EACH direction of the link at once",
-            "peak": round(peak, 2), "peak_source": "best of: one kernel in place on page-locked memory (this run), DMA engines both ways at once (tools/ubench_pcie_bidir)",
-            "dma_both_ways_per_direction": dma, "dma_one_way": one_way, "spec_per_direction": 64.0,
+            "peak": link, "peak_link": link, "peak_is": "PCIe gen 5 x16 per direction on paper", "dma_one_way": one_way, "dma_duplex": duplex,
+            "reference_only_one_kernel_in_place": ceil.get("product_pinned_route_in_place"),
             "achieved": {"page_locked_in_place": {k: v["GBps_payload"] for k, v in hpp.items()},
                          "pageable_staged": {k: v["GBps_payload"] for k, v in hp.items() if int(k) >= (1 << 20)}},
-            "frac": {"page_locked_in_place": {k: round(v["GBps_payload"] / peak, 4) for k, v in hpp.items()},
-                     "pageable_staged": {k: round(v["GBps_payload"] / peak, 4) for k, v in hp.items() if int(k) >= (1 << 20)}},
+            "frac_of_link": {"page_locked_in_place": fracs(hpp, link), "pageable_staged": fracs(hp, link)},
+            "frac_of_dma_one_way": {"page_locked_in_place": fracs(hpp, one_way), "pageable_staged": fracs(hp, one_way)},
+            "frac_of_dma_duplex": {"page_locked_in_place": fracs(hpp, duplex), "pageable_staged": fracs(hp, duplex)},
+            "feed_kernel_source_hash": M.feed_kernel_source_hash(), "kernel_source_hash": M.kernel_source_hash(),
         }
 
     # ---- config 1: 4 KiB framed blob, decrypt (plumbing)

@@ -7,6 +7,7 @@
 #   pcie        modbench --route <kind> under rocprofv3 --kernel-trace, joined with the library's launch list, priced against `ceiling` -> r06_pcie_route_*.json
 #   bench       python3 bench.py (the driver's line) and tools/profile.sh r06 (rocprofv3 stats + PMC)                               -> r06_bench.json, r06_*
 #   gpus2       python3 bench.py --gpus 2 by itself on the one GPU                                                                  -> r06_bench_gpus2_by_itself.json
+#   configs     BASELINE configs 1, 4, 5 end to end + the host-buffer rates with roofline_pcie                                      -> r06_configs.json
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out
@@ -36,5 +37,8 @@ bench)
   tail -5 $O/r06_profile.log ;;
 gpus2)
   python3 bench.py --gpus 2 --force-device 0 --steps 3 --warmup 1 --part-bytes 335544320 > $O/r06_bench_gpus2_by_itself.json ;;
-*) echo "blocks: ceiling fileroutes pcie bench gpus2"; exit 1 ;;
+configs)
+  python3 tools/bench_configs.py --out $O/r06_configs.json > $O/r06_configs.log 2>&1
+  tail -3 $O/r06_configs.log ;;
+*) echo "blocks: ceiling fileroutes pcie bench gpus2 configs"; exit 1 ;;
 esac
