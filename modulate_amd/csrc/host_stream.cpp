@@ -1219,11 +1219,14 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     CPU_ZERO(&caller_mask);
     bool have_mask = false;
     if (numa::enabled() && n > kZeroCopyMax) {
+        // (what decides is the side the CPU READS across the socket link: a copy whose source is remote runs at 6-12 GB/s per thread
+        //  instead of 28, one whose destination is remote hardly suffers, profiles/r05_staged_numa.txt)
         const uint8_t *pages = src.mem && !src_direct ? src.mem : dst.mem && !dst_direct ? dst.mem : nullptr;
-        if (pages) {
-            copy_node = numa::node_of_address(pages + n / 2);
-            have_mask = ::sched_getaffinity(0, sizeof caller_mask, &caller_mask) == 0;
-        }
+        if (!src.mem && dst.mem) { // a part file read into memory: where the file's cached pages are (pread is the remote read then)
+            copy_node = numa::node_of_file_page(src.fd, src.base + n / 2);
+            if (copy_node < 0 && pages) copy_node = numa::node_of_address(pages + n / 2);
+        } else if (pages) copy_node = numa::node_of_address(pages + n / 2);
+        if (copy_node >= 0) have_mask = ::sched_getaffinity(0, sizeof caller_mask, &caller_mask) == 0;
     }
     const int gpu_node = copy_node >= 0 ? device_numa_node(dev) : -1;
     const int set = copy_node >= 0 && copy_node < kNodeSets - 1 && gpu_node >= 0 && copy_node != gpu_node && have_mask ? 1 + copy_node : 0;

@@ -3,6 +3,7 @@
 
 #include <sched.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -143,6 +144,18 @@ int node_of_address(const void *p)
     int node = -1;
     // (no libnuma in the image: the system call itself; 3 = MPOL_F_NODE | MPOL_F_ADDR)
     if (::syscall(SYS_get_mempolicy, &node, nullptr, 0ul, const_cast<void *>(p), 3ul) != 0) return -1;
+    return node;
+}
+
+int node_of_file_page(int fd, unsigned long long offset)
+{
+    struct stat st;
+    if (fd < 0 || ::fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || (unsigned long long)st.st_size <= offset) return -1;
+    const unsigned long long page = (unsigned long long)::sysconf(_SC_PAGESIZE);
+    void *m = ::mmap(nullptr, (size_t)page, PROT_READ, MAP_SHARED, fd, (off_t)(offset & ~(page - 1)));
+    if (m == MAP_FAILED) return -1;
+    const int node = node_of_address(m);
+    ::munmap(m, (size_t)page);
     return node;
 }
 

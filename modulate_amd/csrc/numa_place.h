@@ -41,6 +41,9 @@ int run_on_node(const std::string &sysfs, int node);
 
 // NUMA node the page holding `p` lives on (get_mempolicy; a page not yet present is faulted in by the question).  -1 = unknown.
 int node_of_address(const void *p);
+// NUMA node of the page-cache page that holds byte `offset` of the open file `fd` (the page is mapped for a moment and asked about;
+// a page not in the cache is read by the question, and then lives wherever the kernel put it).  -1 = unknown / beyond the file's end.
+int node_of_file_page(int fd, unsigned long long offset);
 // Moves the calling (worker) thread to the CPUs of `node` that `allowed` -- the affinity mask of the thread it works for --
 // contains; unlike run_on_node this can take a thread from one node to another.  The node's CPU list is read from /sys once per
 // node.  0 = done, -1 = left as it was.

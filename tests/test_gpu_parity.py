@@ -581,6 +581,21 @@ for n in ((3 << 20) + 1, (64 << 20) + 5, (20 << 20) - 3):
     assert np.array_equal(M.cycle_host(got, M.KEY_PS4), pt), n
 took = M.host_pool_stats()["calls_on_another_nodes_set"] - before
 assert took == 6, took
+# round 6: a part FILE whose cached pages live over there (written from this thread on tmpfs) is read by that node's set too -- pread is
+# the copy that would otherwise read across the socket link -- whether it ends in pageable memory or in page-locked memory next to the GPU
+import tempfile
+n = (48 << 20) + 7
+pt = O.splitmix_bytes(n, 5)
+want = O.cycle(pt.copy(), O.KEY_PS4)
+with tempfile.NamedTemporaryFile(dir="/dev/shm", suffix=".part") as f:
+    pt.tofile(f.name)
+    before = M.host_pool_stats()["calls_on_another_nodes_set"]
+    assert np.array_equal(M.cycle_file_to_host(f.name, n, M.KEY_PS4), want)
+    pb = M.PinnedBuffer(n + 16, near_device=0)
+    M.cycle_file_to_host(f.name, n, M.KEY_PS4, out=pb.array[3:3 + n])
+    assert np.array_equal(pb.array[3:3 + n], want)
+    pb.free()
+    assert M.host_pool_stats()["calls_on_another_nodes_set"] - before == 2
 print("OTHER_NODE_OK", gpu_node, others[0])
 """
 
@@ -589,7 +604,8 @@ def test_staged_route_when_the_callers_pages_are_on_the_other_socket(gpu):
     """Round 5 (profiles/r05_staged_numa.txt): a caller whose pageable pages live on another NUMA node than the GPU's gets that
     node's staging set -- slots placed there by the library (reserve, mbind, touch, hipHostRegister), workers bound there.  A child
     moves itself to the other node's CPUs, allocates there, and must get the oracle's bytes and the counter that says which set
-    served it.  Skips itself on a one-node machine."""
+    served it.  Round 6: the same for a part FILE whose cached pages live there (the set follows the side the CPU would read across
+    the socket link).  Skips itself on a one-node machine."""
     r = subprocess.run([sys.executable, "-c", _OTHER_NODE_CHILD % ROOT], capture_output=True, text=True, env=dict(os.environ), timeout=600)
     assert r.returncode == 0 and ("OTHER_NODE_OK" in r.stdout or "OTHER_NODE_SKIP" in r.stdout), r.stdout[-2000:] + r.stderr[-2000:]
 
