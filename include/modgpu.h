@@ -210,10 +210,10 @@ int modgpu_cycle_parts_device(void *const *dev_parts, const uint64_t *sizes, con
 /* ---- part files streamed through the GPU ----------------------------
  * The reference reads a part with one fread into the concatenated buffer (CArk.cpp:751) and writes
  * a slice with one fwrite (CArk.cpp:883).  These do the same transfers with the cipher applied on
- * the way, overlapped: pread -> pinned -> H2D -> kernel -> D2H -> pinned -> pwrite / caller memory,
- * several chunks in flight, without a pageable staging copy (and with no host copy at all on the
- * memory side when that memory is pinned).  Each call is one stream whose first byte has
- * keystream position stream_off (0 = a part's own Cycle). */
+ * the way, overlapped, several chunks in flight: pread into a page-locked slot -> the kernel cycles the
+ * slot across PCIe (file -> memory below 2 GiB: ONE kernel launch for the whole call) -> copy / pwrite
+ * out; page-locked caller memory on the SOURCE side is DMA'd from where it lies.  Each call is one
+ * stream whose first byte has keystream position stream_off (0 = a part's own Cycle). */
 
 /* Whole file src_path -> dst_path (created / truncated).  The two may name the same file, by any
  * spelling (compared by device and inode): it is then cycled in place.
