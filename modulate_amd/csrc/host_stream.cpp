@@ -976,11 +976,10 @@ RoutePlan plan_route(CallCtx &c)
     p.chunk = n <= chunk_min ? std::max<uint64_t>(n, 1ull << 20) : std::min<uint64_t>(kChunk, std::max<uint64_t>(chunk_min, ((n / split) + 0xFFFFF) & ~0xFFFFFull));
     p.chunk = std::min<uint64_t>(p.chunk, kChunk);
     // Default routes (profiles/r03_file_routes.txt, r06_file_routes.txt): pageable memory and files are copied / read into a pinned
-    // slot and cycled there across PCIe; a file that ends in page-locked caller memory is read straight into that memory and cycled
-    // where it lies; page-locked caller memory that ends in a file is DMA'd.  (Testing flavour, staged mode 1: the DMA form -- H2D,
-    // kernel in HBM, D2H -- of the first two.)
-    // A part file that ends in page-locked memory: below 2 GiB through the slots like any other destination (the host-fed kernel wins
-    // there); from 2 GiB up -- or with file_feed off -- read straight into that memory and cycled where it lies, a launch per chunk.
+    // slot and cycled there across PCIe; page-locked caller memory that ends in a file is DMA'd.  (Testing flavour, staged mode 1: the
+    // DMA form -- H2D, kernel in HBM, D2H -- of the first.)  A part file that ends in PAGE-LOCKED memory: below 2 GiB through the slots
+    // like any other destination (the host-fed kernel wins there); from 2 GiB up -- or with file_feed off -- read straight into that
+    // memory and cycled where it lies, a launch per chunk.
     const bool file_to_locked_pages = c.dst_direct && !src.mem && !c.identity && staged_mode() != 1;
     const bool through_slots = file_to_locked_pages && kFeed != 0 && kFileFeed != 0 && staged_mode() == 0 && n < kFeedBelow;
     p.route = file_to_locked_pages && !through_slots                               ? Route::in_dst
