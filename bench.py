@@ -280,6 +280,9 @@ def main():
     if M.device_count() < 1:
         raise SystemExit("no HIP device: bench.py measures the HIP path only")
     dev = local_rank if a.force_device is None else a.force_device
+    if dev >= M.device_count():
+        raise SystemExit(f"rank {rank}: HIP device {dev} does not exist ({M.device_count()} visible): --gpus N wants N GPUs on this node "
+                         f"(--force-device D rehearses N ranks on one)")
 
     # A caller that brings its OWN device memory (hipMalloc / hipMemcpy of its own) gets the library's device preparation and wake-up
     # by name: modgpu_prepare (ABI 8).  Measured in a fresh child process -- a process's first launch is the point -- before this
