@@ -237,11 +237,18 @@ const int g_staging_atfork = ::pthread_atfork(nullptr, nullptr, [] {
 });
 std::atomic<uint64_t> g_pool_spawned{0}, g_pool_tasks{0}, g_slot_waits{0}, g_calls_in_flight{0}, g_calls_overlapped{0}, g_node_set_calls{0};
 
+// A device whose host-fed kernel stopped responding (see feed_stop): its staging sets take no further call -- whatever is queued behind
+// a kernel that never ends would never run --, the slots the lost call held are never handed out again, and Cycle serves the device's
+// callers from the host loop from then on (the attempt fails before it touches anything: modgpu_cycle_auto_host's second branch).
+std::atomic<bool> g_device_lost[kMaxDevices];
+int fail_lost() { return fail(MODGPU_ERR_HIP, "this device's host-buffer routes were abandoned: a host-fed kernel stopped responding"); }
+
 // Slots a call owns, given back (and waiters woken) when the call ends, whichever way.
 struct SlotLease {
     Staging &s;
-    std::vector<int> ids;
-    explicit SlotLease(Staging &st) : s(st) {}
+    const int dev;
+    std::vector<int> ids; // (empty after acquire: the device was lost while this call waited)
+    SlotLease(Staging &st, int dev_) : s(st), dev(dev_) {}
     SlotLease(const SlotLease &) = delete;
     SlotLease &operator=(const SlotLease &) = delete;
     // takes up to `want` slots in whole groups of `group`; waits while fewer than one group is free.  A call that asks for ONE
@@ -257,10 +264,12 @@ struct SlotLease {
             for (int i = 0; i < limit; ++i) f += s.busy[i] ? 0 : 1;
             return f;
         };
-        if (n_free() < group) {
+        auto lost = [&] { return g_device_lost[dev].load(std::memory_order_acquire); };
+        if (n_free() < group && !lost()) {
             g_slot_waits.fetch_add(1, std::memory_order_relaxed);
-            s.slot_cv.wait(lock, [&] { return n_free() >= group; });
+            s.slot_cv.wait(lock, [&] { return n_free() >= group || lost(); });
         }
+        if (lost()) return;
         const int take = std::min(want, n_free()) / group * group;
         for (int k = 0; k < limit && (int)ids.size() < take; ++k) {
             const int i = single ? limit - 1 - k : k;
@@ -272,7 +281,7 @@ struct SlotLease {
     }
     ~SlotLease()
     {
-        if (ids.empty()) return;
+        if (ids.empty() || g_device_lost[dev].load(std::memory_order_acquire)) return; // (a lost device's slots stay taken: a kernel may still be at work in them)
         {
             std::lock_guard<std::mutex> lock(s.mu);
             for (int i : ids) s.busy[i] = false;
@@ -448,6 +457,7 @@ struct Job {
     uint32_t *feed_ready = nullptr, *feed_done = nullptr, *feed_abort = nullptr; // host addresses
     hipStream_t feed_stream = nullptr;
     std::atomic<bool> feed_launched{false}; // the kernel is on feed_stream (it is launched while the pipelines copy their first chunks in)
+    int dev = 0;                            // logical device (whose host-buffer routes are abandoned if the kernel stops responding)
     int copy_node = -1; // NUMA node the caller's pages live on (-1: unknown, or no pageable memory endpoint): picks the staging set (g_staging)
     cpu_set_t caller_mask; // the calling thread's affinity mask: a worker is never put on a CPU the caller may not use
     bool have_mask = false;
@@ -483,13 +493,26 @@ std::vector<Piece> cut_stream(uint64_t n, uint64_t chunk, int pipes, uint64_t ra
 
 constexpr int kStopped = -1000; // run_pipe: another pipeline of the call failed and this one stopped early -- not an error of its own
 
+// How long the host puts up with a host-fed kernel that neither finishes a chunk nor ends.  The kernel itself gives a chunk up after
+// its patience P and is gone microseconds later, so a healthy call never waits anywhere near 4 P + grace (50 s by default) for one chunk;
+// a kernel that is still "running" by then has stopped responding (a workgroup wedged at a barrier: what check_isa.py's EXEC rule keeps
+// out of a build, and what a host must survive anyway).
+std::chrono::duration<double> feed_grace()
+{
+    const double p = (double)kFeedPatienceTicks * 1e-8;
+    return std::chrono::duration<double>(std::min(10.0, std::max(1.0, 25.0 * p)));
+}
+std::chrono::duration<double> feed_host_deadline() { return std::chrono::duration<double>(4.0 * (double)kFeedPatienceTicks * 1e-8) + feed_grace(); }
+
 // Waits until the host-fed kernel has marked chunk c done.  Spins (the wait is tens of microseconds while the call is healthy); every
 // ~50 us it looks at the call -- a sibling pipeline that failed --, every millisecond at the kernel's stream -- a kernel that has ended
 // without finishing the chunk gave up (it waited too long for the host) or died, and either way the chunk will never be done by it --, and
-// from then on it gives the CPU away between looks (a host with fewer CPUs than pipelines must not burn its quota here).
+// from then on it gives the CPU away between looks (a host with fewer CPUs than pipelines must not burn its quota here).  A kernel that
+// neither finishes the chunk nor ends within feed_host_deadline() has stopped responding: the call is lost like any other.
 int feed_wait(Job &j, uint64_t c)
 {
     uint32_t spins = 0;
+    const auto began = std::chrono::steady_clock::now();
     while (__atomic_load_n(&j.feed_done[c], __ATOMIC_ACQUIRE) == 0u) {
         _mm_pause();
         if ((++spins & 1023u) != 0) continue;
@@ -498,6 +521,8 @@ int feed_wait(Job &j, uint64_t c)
         const hipError_t q = hipStreamQuery(j.feed_stream);
         if (q == hipErrorNotReady) {
             (void)hipGetLastError();
+            if (std::chrono::steady_clock::now() - began > feed_host_deadline())
+                return fail(MODGPU_ERR_HIP, "the host-fed kernel stopped responding (it neither finished the chunk nor ended)");
             std::this_thread::yield();
             continue;
         }
@@ -506,6 +531,34 @@ int feed_wait(Job &j, uint64_t c)
                                : fail_hip(q, "hipStreamQuery (host-fed kernel)");
     }
     return MODGPU_OK;
+}
+
+// Makes sure the call's host-fed kernel is gone: raises abort (a healthy kernel leaves at its next look, microseconds to milliseconds) and
+// waits for its stream to go idle -- but not for ever.  A kernel still there after the grace period will not leave: the device's
+// host-buffer routes are abandoned (g_device_lost) instead of this thread hanging in hipStreamSynchronize with it.  Returns false then.
+bool feed_stop(Job &j)
+{
+    __atomic_store_n(j.feed_abort, 1u, __ATOMIC_RELEASE);
+    if (!j.feed_launched.load(std::memory_order_acquire)) return true;
+    const auto began = std::chrono::steady_clock::now();
+    const auto until = began + feed_grace();
+    for (;;) {
+        if (g_device_lost[j.dev].load(std::memory_order_acquire)) return false; // (a sibling pipeline has found out already)
+        const hipError_t q = hipStreamQuery(j.feed_stream);
+        if (q != hipErrorNotReady) {
+            (void)hipGetLastError();
+            return true;
+        }
+        (void)hipGetLastError();
+        const auto now = std::chrono::steady_clock::now();
+        if (now > until) break;
+        if (now - began < std::chrono::microseconds(300)) // (the normal case: the kernel is on its way out -- a few microseconds)
+            for (int k = 0; k < 64; ++k) _mm_pause();
+        else std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    g_device_lost[j.dev].store(true, std::memory_order_release);
+    trace(MODGPU_TRACE_FAILED, -1, 0, 99);
+    return false;
 }
 
 // ---- one pipeline -----------------------------------------------------------------------------------------------------------------
@@ -722,11 +775,9 @@ int run_pipe(Staging &s, const int *slots, int ring, Job &j, uint64_t first, uin
     if (rc != MODGPU_OK) { // nothing of this call may still be running against the caller's memory (or its slots) once we return
         if (rc != kStopped) j.failed.store(true, std::memory_order_release);
         const std::string keep = t_err;
-        if (j.fed()) { // the kernel leaves at its next look at the flag; chunks it has not finished stay undone
-            __atomic_store_n(j.feed_abort, 1u, __ATOMIC_RELEASE);
-            (void)hipStreamSynchronize(j.feed_stream);
-        }
-        for (int k = 0; k < ring; ++k) (void)hipStreamSynchronize(s.stream[slots[k]]);
+        if (j.fed()) (void)feed_stop(j); // the kernel leaves at its next look at the flag; chunks it has not finished stay undone
+        for (int k = 0; k < ring; ++k)
+            if (!j.fed() || s.stream[slots[k]] != j.feed_stream) (void)hipStreamSynchronize(s.stream[slots[k]]); // (never wait unboundedly on the kernel's own stream)
         for (hipStream_t st : j.lanes) (void)hipStreamSynchronize(st);
         (void)hipGetLastError();
         t_err = keep;
@@ -906,8 +957,9 @@ int injected_here() { return fail(MODGPU_ERR_HIP, "injected failure (modgpu_debu
 // selectable).  One launch + one sync; the kernel reads and writes the pages across PCIe itself (they are device-visible).
 int in_place_on_locked_pages(CallCtx &c)
 {
-    SlotLease lease(c.s);
+    SlotLease lease(c.s, c.dev);
     lease.acquire(1, 1);
+    if (lease.ids.empty()) return fail_lost();
     const int slot = lease.ids[0];
     int rc = staging_reserve(c.s, lease.ids, 0, false, false);
     if (rc) return rc;
@@ -935,8 +987,9 @@ int in_place_on_locked_pages(CallCtx &c)
 int one_slot_call(CallCtx &c)
 {
     Staging &s = c.s;
-    SlotLease lease(s);
+    SlotLease lease(s, c.dev);
     lease.acquire(1, 1);
+    if (lease.ids.empty()) return fail_lost();
     const int slot = lease.ids[0];
     int rc = staging_reserve(s, lease.ids, c.n, false, true);
     if (rc) return rc;
@@ -1060,17 +1113,15 @@ struct FeedCall {
     void finish(int rc)
     {
         Staging &s = c.s;
-        if (rc == MODGPU_OK) {
-            // every chunk is done and drained: the kernel has drawn its last ticket and leaves by itself.  (An error here cannot undo the
-            //  result, which is whole in the destination: it is cleared, and the next call on this device meets whatever is wrong with it.)
-            if (hipStreamSynchronize(job.feed_stream) != hipSuccess) (void)hipGetLastError();
-        } else { // whichever pipeline failed has told the kernel to leave and waited for it; make sure before the slots go back
-            __atomic_store_n(job.feed_abort, 1u, __ATOMIC_RELEASE);
-            const std::string keep = t_err;
-            (void)hipStreamSynchronize(job.feed_stream);
-            (void)hipGetLastError();
-            t_err = keep;
-        }
+        // rc == OK: every chunk is done and drained, the kernel has drawn its last ticket and leaves by itself (an error of the stream here
+        // cannot undo the result, which is whole in the destination: the next call on this device meets whatever is wrong with it).
+        // Otherwise whichever pipeline failed has told the kernel to leave and waited for it; make sure before the slots go back.  Either way
+        // the wait is bounded: a kernel that does not leave costs the device its host-buffer routes (feed_stop), not this thread.
+        const std::string keep = t_err;
+        const bool gone = feed_stop(job);
+        (void)hipGetLastError();
+        t_err = keep;
+        if (!gone) return; // (slots, flag words and counters stay with the kernel that would not leave: SlotLease keeps them out of circulation)
         // the counters go back to zero behind the call (asynchronously, on the slot's own stream: in front of its next launch)
         if (hipMemsetAsync(s.feed_work[lead_slot], 0, (chunks + 2) * sizeof(uint32_t), job.feed_stream) != hipSuccess) {
             (void)hipGetLastError();
@@ -1112,6 +1163,7 @@ int pipelined_call(CallCtx &c)
     const uint64_t n_chunks = (c.n + plan.chunk - 1) / plan.chunk;
     Job job(c.src, c.dst, c.n, plan.chunk, c.key, c.stream_off);
     job.route = plan.route;
+    job.dev = c.dev;
     c.through_slots = plan.route == Route::feed || plan.route == Route::slot_kernel;
     int pipes, ring;
     if (c.all_direct && c.src.mem && c.dst.mem) { // no host work at all: one thread keeps a ring of slots busy
@@ -1126,8 +1178,9 @@ int pipelined_call(CallCtx &c)
     if (c.dst.fd >= 0 && c.n >= (8ull << 20)) (void)::posix_fallocate(c.dst.fd, (off_t)c.dst.base, (off_t)c.n);
     // this call's slots: what it would like, or as many whole pipelines as are free right now (another caller may be at work
     // on this GPU), at least one
-    SlotLease lease(s);
+    SlotLease lease(s, c.dev);
     lease.acquire(pipes * ring, ring);
+    if (lease.ids.empty()) return fail_lost();
     pipes = (int)lease.ids.size() / ring;
     job.set_plan(cut_stream(c.n, plan.chunk, pipes, plan.memory_schedule && !feed ? kRamp : 0));
     job.copy_node = c.copy_node;
@@ -1211,6 +1264,7 @@ int stream_impl(const Endpoint &src, const Endpoint &dst, uint64_t n, int32_t ke
     const bool in_place = src.mem && src.mem == dst.mem;
     if (identity && in_place) return MODGPU_OK;
     if (dev >= kMaxDevices) return fail(MODGPU_ERR_INVALID, "device index beyond staging table");
+    if (g_device_lost[dev].load(std::memory_order_acquire)) return fail_lost(); // (before anything of the caller's is touched)
     const bool src_direct = src.mem && src.pinned, dst_direct = dst.mem && dst.pinned;
     // which of the device's staging sets: the one on the node the caller's PAGEABLE pages live on, if that is not the GPU's own
     int copy_node = -1;
@@ -1282,7 +1336,7 @@ int modgpu_debug_hold_slots(int device, int count)
     std::lock_guard<std::mutex> lock(mu);
     held[device].reset();
     if (count <= 0) return 0;
-    held[device].reset(new SlotLease(staging_of(device, 0)));
+    held[device].reset(new SlotLease(staging_of(device, 0), device));
     held[device]->acquire(count, 2);
     return (int)held[device]->ids.size();
 }

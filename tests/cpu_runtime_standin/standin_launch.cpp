@@ -102,12 +102,22 @@ hipError_t modgpu_launch_cycle_queue(const CycleQueueArgs &a, uint32_t, hipStrea
 // chunk in its slot from the launch arguments alone, mark it `done`.  Runs WHILE the library's pipelines copy in and out, as the kernel does.
 namespace {
 std::atomic<unsigned long long> g_feed_launches{0}, g_feed_gave_up{0};
+// modgpu_shim_wedge_next_feed(1): the next host-fed "kernel" stops responding half-way -- it neither finishes its chunks nor ends, whatever
+// the host's abort word says (a workgroup stuck at a barrier) -- until modgpu_shim_release_wedged() lets the stream's thread go.
+std::atomic<int> g_wedge_next{0};
+std::atomic<bool> g_wedge_release{false};
 void run_feed(void *arg)
 {
     CycleFeedArgs *a = static_cast<CycleFeedArgs *>(arg);
     const uint64_t chunks = (a->n + a->chunk_bytes - 1) / a->chunk_bytes;
     bool gave_up = false;
+    const bool wedge = g_wedge_next.exchange(0) != 0;
     for (uint64_t c = 0; c < chunks && !gave_up; ++c) {
+        if (wedge && c == chunks / 2) {
+            while (!g_wedge_release.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            delete a; // (nothing of the call is touched any more: the library has long abandoned it)
+            return;
+        }
         const auto since = std::chrono::steady_clock::now();
         while (std::atomic_ref<const uint32_t>(a->ready[c]).load(std::memory_order_acquire) == 0u) {
             const double waited_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - since).count();
@@ -138,6 +148,8 @@ hipError_t modgpu_launch_cycle_feed(const CycleFeedArgs &a, uint32_t, hipStream_
     shim::enqueue(stream, run_feed, new CycleFeedArgs(a));
     return hipSuccess;
 }
+extern "C" void modgpu_shim_wedge_next_feed(int on) { g_wedge_next.store(on ? 1 : 0); }
+extern "C" void modgpu_shim_release_wedged(void) { g_wedge_release.store(true, std::memory_order_release); }
 extern "C" unsigned long long modgpu_shim_feed_launches(void) { return g_feed_launches.load(); }
 extern "C" unsigned long long modgpu_shim_feed_gave_up(void) { return g_feed_gave_up.load(); }
 

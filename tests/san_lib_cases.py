@@ -533,3 +533,42 @@ def test_calls_leave_the_callers_device_alone(hooks, lib):
     b.free()
     assert lib.modgpu_shim_get_device() == 5
     assert lib.modgpu_shim_set_device(0) == 0
+
+
+def test_zz_a_host_fed_kernel_that_stops_responding_costs_the_device_not_the_process(hooks, lib):
+    """LAST in this file (it costs device 7 its host-buffer routes for the rest of the process).  A host-fed kernel that neither
+    finishes its chunks nor ends -- a workgroup wedged at a barrier; what check_isa.py's EXEC rule keeps out of a build, and what a
+    host must survive anyway (feed_wait would poll hipErrorNotReady for ever).  The pipelines give the call up after the
+    host-side deadline (4 x the kernel's patience + a grace period), nobody waits unboundedly on the kernel's stream, the call is
+    finished by the host loop -- Cycle's bytes are the reference's --, the device's routes are abandoned (its slots are never handed
+    out again), the next Cycle on it is served by the host loop, the GPU-only entry point says why, and the other devices work on."""
+    import time
+    lib.modgpu_shim_wedge_next_feed.argtypes = [ctypes.c_int]
+    pt = O.splitmix_bytes((12 << 20) + 5, 123)
+    w = want(pt, M.KEY_PS4)
+    M.debug_set_host_tunable("feed_patience_ms", 40)  # deadline 4 x 40 ms + 1 s of grace
+    try:
+        before = M.path_stats()
+        lib.modgpu_shim_wedge_next_feed(1)
+        t0 = time.perf_counter()
+        buf = pt.copy()
+        M.cycle_auto_host(buf, M.KEY_PS4, device=7)
+        took = time.perf_counter() - t0
+        after = M.path_stats()
+        assert np.array_equal(buf, w) and after["midcall_rescues"] == before["midcall_rescues"] + 1, (before, after)
+        assert 1.0 < took < 30.0, took  # it waited for the deadline and the grace period, and for nothing else
+        # the device is gone for host buffers: Cycle falls to the host loop before it touches anything, the strict entry point explains
+        buf = pt.copy()
+        M.cycle_auto_host(buf, M.KEY_PS4, device=7)
+        assert np.array_equal(buf, w) and M.path_stats()["auto_fallbacks"] == after["auto_fallbacks"] + 1
+        with pytest.raises(M.ModGpuError) as e:
+            M.cycle_host(pt.copy(), M.KEY_PS4, device=7)
+        assert e.value.code == 3 and "abandoned" in str(e.value)
+        small = pt[:100_000].copy()
+        with pytest.raises(M.ModGpuError):
+            M.cycle_host(small, M.KEY_PS4, device=7)  # the one-slot route too
+        # its neighbours are untouched
+        assert np.array_equal(M.cycle_host(pt.copy(), M.KEY_PS4, device=6), w) and M.last_launch()["variant"] == 4
+    finally:
+        M.debug_set_host_tunable("feed_patience_ms", 10000)
+        lib.modgpu_shim_release_wedged()

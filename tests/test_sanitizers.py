@@ -33,7 +33,7 @@ def test_host_logic_under_asan_ubsan():
     assert "passed" in r.stdout
 
 
-def _san_lib_cases(preload, lib, extra_env, select=(), expect="15 passed"):
+def _san_lib_cases(preload, lib, extra_env, select=(), expect="16 passed"):
     from oracle import oracle as O
     O.build(ref=False)  # here, not in the child: the compiler must not run under a preloaded sanitizer runtime
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "modulate_amd", "csrc"), "sanitize-lib"])
