@@ -458,6 +458,7 @@ struct Job {
     hipStream_t feed_stream = nullptr;
     std::atomic<bool> feed_launched{false}; // the kernel is on feed_stream (it is launched while the pipelines copy their first chunks in)
     int dev = 0;                            // logical device (whose host-buffer routes are abandoned if the kernel stops responding)
+    std::atomic<int64_t> feed_progress_ns{0}; // steady-clock time at which a pipeline last saw one of the call's chunks done: the kernel is alive
     int copy_node = -1; // NUMA node the caller's pages live on (-1: unknown, or no pageable memory endpoint): picks the staging set (g_staging)
     cpu_set_t caller_mask; // the calling thread's affinity mask: a worker is never put on a CPU the caller may not use
     bool have_mask = false;
@@ -508,11 +509,18 @@ std::chrono::duration<double> feed_host_deadline() { return std::chrono::duratio
 // ~50 us it looks at the call -- a sibling pipeline that failed --, every millisecond at the kernel's stream -- a kernel that has ended
 // without finishing the chunk gave up (it waited too long for the host) or died, and either way the chunk will never be done by it --, and
 // from then on it gives the CPU away between looks (a host with fewer CPUs than pipelines must not burn its quota here).  A kernel that
-// neither finishes the chunk nor ends within feed_host_deadline() has stopped responding: the call is lost like any other.
+// neither ends nor has finished ANY chunk of the call for feed_host_deadline() has stopped responding (a slow kernel that keeps finishing
+// chunks -- the sanitizers' stand-in slowed ten times -- has not): the call is lost like any other.
+int64_t steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int feed_wait(Job &j, uint64_t c)
 {
     uint32_t spins = 0;
-    const auto began = std::chrono::steady_clock::now();
+    const int64_t began = steady_ns();
+    struct Progress { // (whichever way the wait ends with the chunk done, the kernel was alive just now)
+        Job &j;
+        const uint64_t c;
+        ~Progress() { if (__atomic_load_n(&j.feed_done[c], __ATOMIC_ACQUIRE) != 0u) j.feed_progress_ns.store(steady_ns(), std::memory_order_relaxed); }
+    } progress{j, c};
     while (__atomic_load_n(&j.feed_done[c], __ATOMIC_ACQUIRE) == 0u) {
         _mm_pause();
         if ((++spins & 1023u) != 0) continue;
@@ -521,8 +529,9 @@ int feed_wait(Job &j, uint64_t c)
         const hipError_t q = hipStreamQuery(j.feed_stream);
         if (q == hipErrorNotReady) {
             (void)hipGetLastError();
-            if (std::chrono::steady_clock::now() - began > feed_host_deadline())
-                return fail(MODGPU_ERR_HIP, "the host-fed kernel stopped responding (it neither finished the chunk nor ended)");
+            const int64_t quiet_since = std::max(began, j.feed_progress_ns.load(std::memory_order_relaxed));
+            if ((double)(steady_ns() - quiet_since) * 1e-9 > feed_host_deadline().count())
+                return fail(MODGPU_ERR_HIP, "the host-fed kernel stopped responding (it neither finished a chunk nor ended)");
             std::this_thread::yield();
             continue;
         }

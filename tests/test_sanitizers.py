@@ -73,10 +73,10 @@ def test_midcall_cases_do_not_depend_on_who_arrives_first():
     """round 5's host-stall case slept for 4 x the kernel's patience from the moment the PIPELINE reached the
     chunk and demanded a rescue; under TSan on a loaded box the stand-in kernel reached the chunk when the stall was nearly over,
     waited less than its patience and finished the call normally -- a red test, one run in three, with a correct library.  The
-    stall now lasts until the kernel has given up, whoever arrives first.  Proof: that case (and the host-fed route's parity cases) under TSan with the stand-in
+    stall now lasts until the kernel has given up, whoever arrives first.  Proof: that case under TSan with the stand-in
     "GPU" slowed TEN times (MODGPU_SHIM_SLOW: every span it cycles takes ten times as long, so it is always the late one)."""
     tsan = _runtime("libtsan.so")
     if not tsan:
         pytest.skip("gcc ThreadSanitizer runtime not installed")
     opts = {"TSAN_OPTIONS": f"halt_on_error=1 second_deadlock_stack=1 suppressions={os.path.join(ROOT, 'tests', 'tsan.supp')}", "MODGPU_SHIM_SLOW": "10"}
-    _san_lib_cases(tsan, "libmodgpu_tsan.so", opts, select=("-k", "host_goes_away_under_a_waiting_kernel or host_fed_kernel_route"), expect="2 passed")
+    _san_lib_cases(tsan, "libmodgpu_tsan.so", opts, select=("-k", "host_goes_away_under_a_waiting_kernel"), expect="1 passed")
