@@ -501,7 +501,7 @@ constexpr int kStopped = -1000; // run_pipe: another pipeline of the call failed
 std::chrono::duration<double> feed_grace()
 {
     const double p = (double)kFeedPatienceTicks * 1e-8;
-    return std::chrono::duration<double>(std::min(10.0, std::max(1.0, 25.0 * p)));
+    return std::chrono::duration<double>(std::min(10.0, std::max(1.0, 10.0 * p)));
 }
 std::chrono::duration<double> feed_host_deadline() { return std::chrono::duration<double>(4.0 * (double)kFeedPatienceTicks * 1e-8) + feed_grace(); }
 
