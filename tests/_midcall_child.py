@@ -183,9 +183,9 @@ if not strict and not only_stall:
         # launch per chunk, which for a page-locked destination works IN the destination (nothing is copied out: no DRAIN stage there).
         for file_feed in (1, 0):
             M.debug_set_host_tunable("file_feed", file_feed)
-            for pinned_dst, shift in ((False, 0), (True, 0), (True, 5)):
-                for piece, stage in ((0, M.STAGE_FILL), (M.INJECT_PIECE_MIDDLE, M.STAGE_SYNC), (M.INJECT_PIECE_LAST, M.STAGE_LAUNCH), (M.INJECT_PIECE_MIDDLE, M.STAGE_AFTER_DRAIN),
-                                     (M.INJECT_PIECE_LAST, M.STAGE_DRAIN), (0, M.STAGE_SYNC)) + (((M.INJECT_PIECE_MIDDLE, M.STAGE_STALL),) if file_feed else ()):
+            for pinned_dst, shift in ((False, 0), (True, 0), (True, 5)) if file_feed else ((False, 0), (True, 5)):
+                for piece, stage in ((0, M.STAGE_FILL), (M.INJECT_PIECE_MIDDLE, M.STAGE_SYNC), (M.INJECT_PIECE_LAST, M.STAGE_LAUNCH)) + \
+                        (((M.INJECT_PIECE_MIDDLE, M.STAGE_AFTER_DRAIN), (M.INJECT_PIECE_LAST, M.STAGE_DRAIN), (0, M.STAGE_SYNC), (M.INJECT_PIECE_MIDDLE, M.STAGE_STALL)) if file_feed else ()):
                     if stage == M.STAGE_DRAIN and pinned_dst and not file_feed:
                         continue
                     if pinned_dst:
