@@ -1212,6 +1212,16 @@ def test_first_host_buffer_calls_of_a_process_on_eight_devices_at_once(gpu):
         assert r.returncode == 0 and "FIRST_CALL_OK" in r.stdout, (k, r.stdout[-2000:] + r.stderr[-2000:])
 
 
+def test_first_calls_of_a_process_of_every_kind_at_once_on_one_device(gpu):
+    """The same question as above asked of ONE device: a fresh process whose first host-buffer calls are six at once, one of each kind
+    (pageable, page-locked in place, file -> pageable, file -> page-locked, header-sized, small pageable) -- the staging context, its
+    slots, workers, flag words and counters are made while the other routes are being set up beside them.  Four fresh processes."""
+    e = dict(os.environ, MODGPU_REQUIRE_GPU="1")
+    for k in range(4):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_first_call_mixed_child.py")], capture_output=True, text=True, env=e, timeout=600)
+        assert r.returncode == 0 and "MIXED_FIRST_OK" in r.stdout, (k, r.stdout[-2000:] + r.stderr[-2000:])
+
+
 def test_eight_workers_on_aliased_devices(gpu):
     """the N-worker sharding code (modgpu_cycle_parts_host, per-device staging contexts)
     executed with 8 workers: 8 logical devices aliased onto this box's GPU.  Parts are independent streams
