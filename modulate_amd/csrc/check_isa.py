@@ -73,7 +73,7 @@ def instructions(fn):
         code = ln.split(";")[0].rstrip()
         if not code.strip():
             continue
-        m = re.match(r"^(\.?[A-Za-z_][\w.$]*):", code)
+        m = re.match(r"^\s*(\.?[A-Za-z_][\w.$]*):", code)
         if m:
             pending.append(m.group(1))
             continue

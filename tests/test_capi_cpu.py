@@ -614,3 +614,68 @@ def test_headers_are_plain_c_and_link_standalone(tmp_path):
                            os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", exe, "-L" + lib, "-lmodgpu", "-Wl,-rpath," + lib])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and ("ABI_SMOKE_OK" in r.stdout or os.environ.get("MODGPU_REQUIRE_GPU", "0") not in ("", "0")), r.stdout + r.stderr
+
+
+def test_codegen_guard_exec_tracking_on_hand_written_snippets():
+    """The barrier rule's control-flow walk on assembly small enough to read: a barrier behind the EXEC restore passes; inside a
+    saveexec region, inside a loop whose lanes leave one by one (s_andn2 exec), or reachable through a branch that skips the restore,
+    it is refused; a region that is closed on both paths of an if / else passes."""
+    ci = _check_isa()
+    ok = """
+        s_and_saveexec_b64 s[4:5], vcc
+        s_cbranch_execz .LBB0_2
+        v_mov_b32 v0, 1
+    .LBB0_2:
+        s_or_b64 exec, exec, s[4:5]
+        s_barrier
+        s_endpgm
+    """
+    assert ci.barriers_at_full_exec("ok", ok) == []
+    inside = ok.replace("        v_mov_b32 v0, 1\n", "        v_mov_b32 v0, 1\n        s_barrier\n")
+    assert any("masked off" in f for f in ci.barriers_at_full_exec("inside", inside))
+    skipped = """
+        s_and_saveexec_b64 s[4:5], vcc
+        s_cbranch_execz .LBB0_3
+        v_mov_b32 v0, 1
+        s_or_b64 exec, exec, s[4:5]
+    .LBB0_3:
+        s_barrier
+        s_endpgm
+    """  # the execz path jumps over the restore: the wave can meet the barrier with the narrowed mask
+    assert any("masked off" in f for f in ci.barriers_at_full_exec("skipped", skipped))
+    lane_loop = """
+    .LBB0_1:
+        v_cmp_eq_u32_e32 vcc, 0, v1
+        s_or_b64 s[6:7], vcc, s[6:7]
+        s_andn2_b64 exec, exec, s[6:7]
+        s_barrier
+        s_cbranch_execnz .LBB0_1
+        s_or_b64 exec, exec, s[6:7]
+        s_endpgm
+    """
+    assert any("masked off" in f for f in ci.barriers_at_full_exec("lane_loop", lane_loop))
+    lane_loop_ok = lane_loop.replace("        s_barrier\n", "").replace("        s_endpgm", "        s_barrier\n        s_endpgm")
+    assert ci.barriers_at_full_exec("lane_loop_ok", lane_loop_ok) == []
+    if_else = """
+        s_and_saveexec_b64 s[4:5], vcc
+        s_xor_b64 s[4:5], exec, s[4:5]
+        s_cbranch_execz .LBB0_2
+        v_mov_b32 v0, 1
+    .LBB0_2:
+        s_or_saveexec_b64 s[4:5], s[4:5]
+        s_xor_b64 exec, exec, s[4:5]
+        s_cbranch_execz .LBB0_4
+        v_mov_b32 v0, 2
+    .LBB0_4:
+        s_or_b64 exec, exec, s[4:5]
+        s_barrier
+        s_endpgm
+    """
+    assert ci.barriers_at_full_exec("if_else", if_else) == []
+    # the SDWA rule on a snippet: one instruction of margin is enough, none is not; a store of the register counts as a read
+    sd = "        v_add_u32_sdwa v5, v1, v2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n"
+    assert ci.sdwa_forwarding_hazards("a", sd + "        v_xor_b32_e32 v6, v5, v7\n        s_endpgm\n")
+    assert ci.sdwa_forwarding_hazards("b", sd + "        global_store_dword v[8:9], v5, off\n        s_endpgm\n")
+    assert not ci.sdwa_forwarding_hazards("c", sd + "        s_nop 0\n        v_xor_b32_e32 v6, v5, v7\n        s_endpgm\n")
+    assert not ci.sdwa_forwarding_hazards("d", sd + "        v_mov_b32_e32 v5, v7\n        s_endpgm\n")  # a whole overwrite is no read
+    assert not ci.sdwa_forwarding_hazards("e", sd + "        v_xor_b32_e32 v6, v4, v7\n        s_endpgm\n")
